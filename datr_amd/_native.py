@@ -1,0 +1,64 @@
+"""ctypes binding of libdatr_hip.so (the C ABI declared in include/datr_hip.h).
+
+The library is built in-tree by `datr_amd/csrc/Makefile` (see __graft_entry__.build) and is
+the ONLY compute backend of the hot path: there is no CPU or eager-PyTorch fallback.  If it is
+missing or an entry point is absent the import of this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdatr_hip.so")
+ABI_VERSION = 1
+
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+
+# name -> argtypes ; every function returns int (DATR_OK / DATR_E*)
+_SIGNATURES = {
+    "datr_msda_forward_f32": [_vp] * 5 + [_i64] * 7 + [_vp, _vp],
+    "datr_msda_forward_f64": [_vp] * 5 + [_i64] * 7 + [_vp, _vp],
+    "datr_msda_backward_f32": [_vp] * 6 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
+    "datr_msda_backward_f64": [_vp] * 6 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
+    "datr_msda_uses_fast_path": [_i64] * 5,
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C datr_amd/csrc`.  datr_amd has no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.datr_abi_version.restype = ctypes.c_int
+    if lib.datr_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"libdatr_hip.so ABI {lib.datr_abi_version()} != expected {ABI_VERSION}")
+    lib.datr_strerror.restype = ctypes.c_char_p
+    lib.datr_strerror.argtypes = [ctypes.c_int]
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what}: {lib.datr_strerror(code).decode()} (code {code})")
+
+
+def current_stream_ptr(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device`, as an integer for ctypes."""
+    return torch.cuda.current_stream(device).cuda_stream

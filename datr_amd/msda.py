@@ -1,0 +1,203 @@
+"""Multi-scale deformable attention: Python mirror of the reference's op package.
+
+Mirrors, name for name and argument for argument:
+  * the pybind11 module `MultiScaleDeformableAttention`
+    (`ms_deform_attn_forward`, `ms_deform_attn_backward`;
+    /root/reference/models/dino/ops/src/vision.cpp:13-16, src/ms_deform_attn.h:21-60,
+    src/cuda/ms_deform_attn_cuda.cu:20-153),
+  * `MSDeformAttnFunction` (/root/reference/models/dino/ops/functions/ms_deform_attn_func.py:21-38),
+  * the `MSDeformAttn` module (/root/reference/models/dino/ops/modules/ms_deform_attn.py:31-126),
+with the compute done by libdatr_hip.so through the C ABI in include/datr_hip.h.  Error
+behaviour follows the reference: non-contiguous tensors raise RuntimeError, CPU tensors raise
+"Not implemented on the CPU" (ms_deform_attn.h:38,60), a batch that is not a multiple of
+min(batch, im2col_step) raises (ms_deform_attn_cuda.cu:50-52).
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _native
+
+__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "MSDeformAttnFunction",
+           "MSDeformAttn"]
+
+
+def _require(t: torch.Tensor, name: str) -> None:
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} tensor has to be contiguous")
+    if not t.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+
+
+def _dims(value, spatial_shapes, sampling_loc, im2col_step):
+    batch, spatial_size, num_heads, channels = value.shape
+    num_levels = spatial_shapes.shape[0]
+    num_query, num_point = sampling_loc.shape[1], sampling_loc.shape[4]
+    step = min(batch, im2col_step)
+    if step <= 0 or batch % step != 0:
+        raise RuntimeError(f"batch({batch}) must divide im2col_step({step})")
+    return batch, spatial_size, num_heads, channels, num_levels, num_query, num_point
+
+
+def _suffix(value: torch.Tensor) -> str:
+    if value.dtype == torch.float32:
+        return "f32"
+    if value.dtype == torch.float64:
+        return "f64"
+    raise RuntimeError(f"ms_deform_attn: unsupported dtype {value.dtype} (float32/float64 only)")
+
+
+def _as_int64(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.int64 else t.to(torch.int64)
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step: int):
+    """-> Tensor [N, Lq, M*D]  (same contract as MSDA.ms_deform_attn_forward)."""
+    for t, nme in ((value, "value"), (spatial_shapes, "spatial_shapes"),
+                   (level_start_index, "level_start_index"), (sampling_loc, "sampling_loc"),
+                   (attn_weight, "attn_weight")):
+        _require(t, nme)
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    sfx = _suffix(value)
+    if sampling_loc.dtype != value.dtype:
+        sampling_loc = sampling_loc.to(value.dtype)
+    if attn_weight.dtype != value.dtype:
+        attn_weight = attn_weight.to(value.dtype)
+    shapes, lsi = _as_int64(spatial_shapes), _as_int64(level_start_index)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        fn = getattr(_native.lib, f"datr_msda_forward_{sfx}")
+        rc = fn(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(),
+                _native.current_stream_ptr(value.device))
+    _native.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step: int):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]."""
+    for t, nme in ((value, "value"), (spatial_shapes, "spatial_shapes"),
+                   (level_start_index, "level_start_index"), (sampling_loc, "sampling_loc"),
+                   (attn_weight, "attn_weight"), (grad_output, "grad_output")):
+        _require(t, nme)
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    sfx = _suffix(value)
+    shapes, lsi = _as_int64(spatial_shapes), _as_int64(level_start_index)
+    grad_value = torch.empty_like(value)            # zero-filled by the library on the stream
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        fn = getattr(_native.lib, f"datr_msda_backward_{sfx}")
+        rc = fn(grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                _native.current_stream_ptr(value.device))
+    _native.check(rc, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_attn]
+
+
+class MSDeformAttnFunction(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                        sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, attn = ctx.saved_tensors
+        grad_value, grad_loc, grad_attn = ms_deform_attn_backward(
+            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_attn, None
+
+
+def _is_power_of_2(n: int) -> bool:
+    if not isinstance(n, int) or n < 0:
+        raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    """Same constructor, parameter names (state_dict keys `sampling_offsets`,
+    `attention_weights`, `value_proj`, `output_proj`), initialisation and forward signature as
+    the reference module (ops/modules/ms_deform_attn.py:31-126)."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(
+                f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a per-head dimension of 16/32/64 takes the "
+                          "row-vectorised gfx950 kernels; other sizes use the generic path.")
+        self.im2col_step = 64
+        self.d_model, self.n_levels = d_model, n_levels
+        self.n_heads, self.n_points = n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # offsets start as a ring of directions (one per head) scaled by the point index
+        nn.init.constant_(self.sampling_offsets.weight, 0.0)
+        angle = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        ring = torch.stack([angle.cos(), angle.sin()], dim=-1)
+        ring = ring / ring.abs().max(dim=-1, keepdim=True)[0]
+        ring = ring.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            ring[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(ring.reshape(-1))
+        nn.init.constant_(self.attention_weights.weight, 0.0)
+        nn.init.constant_(self.attention_weights.bias, 0.0)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.0)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        N, Len_q, _ = query.shape
+        _, Len_in, _ = input_flatten.shape
+        H = self.n_heads
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(N, Len_in, H, self.d_model // H)
+        offsets = self.sampling_offsets(query).view(N, Len_q, H, self.n_levels, self.n_points, 2)
+        weights = self.attention_weights(query).view(N, Len_q, H, self.n_levels * self.n_points)
+        weights = F.softmax(weights, -1).view(N, Len_q, H, self.n_levels, self.n_points)
+        if reference_points.shape[-1] == 2:
+            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] \
+                + offsets / wh[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get "
+                             f"{reference_points.shape[-1]} instead.")
+        if value.dtype == torch.float16:     # amp: the kernels run in fp32, like the reference
+            out = MSDeformAttnFunction.apply(value.float(), input_spatial_shapes,
+                                             input_level_start_index, locations.float(),
+                                             weights.float(), self.im2col_step).to(torch.float16)
+        else:
+            out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                             locations, weights, self.im2col_step)
+        return self.output_proj(out)

@@ -1,0 +1,94 @@
+/*
+ * datr_hip.h -- C ABI of libdatr_hip.so, the MI355X (gfx950) native library behind
+ * datr_amd.  Plain pointers and sizes only; no torch / ATen types.
+ *
+ * Every entry point
+ *   - takes DEVICE pointers unless the parameter name ends in `_host`,
+ *   - enqueues its work on the caller's `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream) and never synchronises the host,
+ *   - keeps no global mutable state and is re-entrant (forward runs on the caller's
+ *     thread, backward on an autograd worker thread in the reference's call pattern:
+ *     /root/reference/models/dino/ops/functions/ms_deform_attn_func.py:21-38),
+ *   - returns DATR_OK or a negative DATR_E* code; `datr_strerror` renders it.
+ *
+ * The reference-side binding a maintainer would write is shown in INTEGRATION.md.
+ */
+#ifndef DATR_HIP_H_
+#define DATR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DATR_OK            0
+#define DATR_EINVAL       -1   /* null pointer / non-positive or inconsistent dimension      */
+#define DATR_EUNSUPPORTED -2   /* shape outside what the kernels index with 32 bits          */
+#define DATR_ELAUNCH      -3   /* hipGetLastError() != hipSuccess after the launch           */
+
+const char *datr_strerror(int code);
+/* ABI version: bumped whenever a signature in this header changes. */
+int datr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention: sampling + aggregation.
+ *
+ * Replaces the two functions the reference's pybind11 module exports
+ *   ms_deform_attn_forward / ms_deform_attn_backward
+ *   (/root/reference/models/dino/ops/src/vision.cpp:13-16,
+ *    /root/reference/models/dino/ops/src/ms_deform_attn.h:21-60,
+ *    host code /root/reference/models/dino/ops/src/cuda/ms_deform_attn_cuda.cu:20-153).
+ *
+ * Layouts, all contiguous:
+ *   value   [N, S, M, D]          S = sum_l H_l*W_l
+ *   shapes  [L, 2] int64 (H_l, W_l)   level_start [L] int64   -- DEVICE memory, as in the
+ *           reference, whose kernels read them in-kernel (ms_deform_im2col_cuda.cuh:274-277)
+ *   loc     [N, Lq, M, L, P, 2]   (x, y) in normalised [0,1] image coordinates
+ *   attn    [N, Lq, M, L, P]
+ *   out / grad_out   [N, Lq, M*D]
+ *
+ * forward : `out` is fully overwritten (no need to zero it).
+ * backward: `grad_value` is zero-filled BY THE LIBRARY on `stream` and then accumulated with
+ *           float atomics (the reference zero-fills with at::zeros_like,
+ *           ms_deform_attn_cuda.cu:121); `grad_loc` and `grad_attn` are fully overwritten.
+ *           Atomic accumulation order is not deterministic, so grad_value is reproducible
+ *           to rounding only -- exactly as in the reference.
+ * The reference's `im2col_step` batching (ms_deform_attn_cuda.cu:50-75) has no effect on
+ * results; the whole batch is one launch here and the divisibility check lives in the
+ * Python mirror (datr_amd/msda.py).
+ * ------------------------------------------------------------------------------------------ */
+int datr_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                          const float *loc, const float *attn,
+                          int64_t N, int64_t S, int64_t M, int64_t D,
+                          int64_t L, int64_t Lq, int64_t P,
+                          float *out, void *stream);
+
+int datr_msda_backward_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                           const int64_t *level_start, const float *loc, const float *attn,
+                           int64_t N, int64_t S, int64_t M, int64_t D,
+                           int64_t L, int64_t Lq, int64_t P,
+                           float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+
+/* Double-precision twins (generic kernels; they exist so the reference's gradcheck-in-double
+ * op test, /root/reference/models/dino/ops/test.py:63-86, can be restated). */
+int datr_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,
+                          const double *loc, const double *attn,
+                          int64_t N, int64_t S, int64_t M, int64_t D,
+                          int64_t L, int64_t Lq, int64_t P,
+                          double *out, void *stream);
+
+int datr_msda_backward_f64(const double *grad_out, const double *value, const int64_t *shapes,
+                           const int64_t *level_start, const double *loc, const double *attn,
+                           int64_t N, int64_t S, int64_t M, int64_t D,
+                           int64_t L, int64_t Lq, int64_t P,
+                           double *grad_value, double *grad_loc, double *grad_attn, void *stream);
+
+/* Which kernel family a float32 call with these dimensions dispatches to:
+ * 1 = row-vectorised gfx950 fast path, 0 = generic one-thread-per-scalar path. */
+int datr_msda_uses_fast_path(int64_t S, int64_t M, int64_t D, int64_t L, int64_t P);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DATR_HIP_H_ */

@@ -1,0 +1,100 @@
+"""Kernel-level timing of the MSDA HIP kernels at BASELINE's call shapes.
+
+    python tools/bench_msda.py [--iters 50] [--dist uniform|model]
+
+`uniform`: loc ~ U[0,1) over the whole image (the reference op test's recipe; worst case for
+cache locality).  `model`: reference points on the pixel grid + the module's initial ring
+offsets (what the encoder produces at initialisation).  Prints one JSON line per shape with
+algorithmic GB/s (bytes defined in DESIGN.md / SURVEY.md 8d).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from datr_amd import msda  # noqa: E402
+
+SHAPES = [(100, 167), (50, 84), (25, 42), (13, 21)]
+
+
+def fwd_bytes(N, S, Lq, M=8, D=32, K=16):
+    return 4 * N * (S * M * D + Lq * M * K * 3 + Lq * M * D)
+
+
+def bwd_bytes(N, S, Lq, M=8, D=32, K=16):
+    return 4 * N * (2 * S * M * D + Lq * (M * D + 2 * M * K * 2 + 2 * M * K))
+
+
+def make_inputs(dev, Lq, dist, seed=3):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shapes = torch.tensor(SHAPES, dtype=torch.int64)
+    S = int(shapes.prod(1).sum())
+    lsi = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    N, M, D, L, P = 2, 8, 32, 4, 4
+    value = torch.rand(N, S, M, D, generator=g) * 0.01
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    if dist == "uniform":
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    else:
+        # reference points: pixel centres of the pyramid (encoder) or uniform boxes (decoder)
+        if Lq == S:
+            refs = []
+            for h, w in SHAPES:
+                ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h,
+                                        torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+                refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+            ref = torch.cat(refs, 0)[None].expand(N, -1, -1)
+        else:
+            ref = torch.rand(N, Lq, 2, generator=g)
+        m = msda.MSDeformAttn(256, 4, 8, 4)
+        off = m.sampling_offsets.bias.detach().view(1, 1, M, L, P, 2)
+        wh = torch.tensor([[w, h] for h, w in SHAPES], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+        loc = ref[:, :, None, None, None, :] + off / wh
+        loc = loc.expand(N, Lq, M, L, P, 2).contiguous()
+    return [t.to(dev).contiguous() for t in (value, shapes, lsi, loc, attn)]
+
+
+def time_fn(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)   # us
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--dist", default="both")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dists = ["uniform", "model"] if args.dist == "both" else [args.dist]
+    for dist in dists:
+        for Lq in (22223, 1100, 900):
+            value, sh, lsi, loc, attn = make_inputs(dev, Lq, dist)
+            N, S = value.shape[0], value.shape[1]
+            go = torch.randn(N, Lq, 256, device=dev)
+            f = lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64)
+            b = lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
+            fm, fmin = time_fn(f, args.iters)
+            bm, bmin = time_fn(b, args.iters)
+            print(json.dumps({
+                "dist": dist, "Lq": Lq,
+                "fwd_us_median": round(fm, 2), "fwd_us_min": round(fmin, 2),
+                "fwd_GBps": round(fwd_bytes(N, S, Lq) / fm / 1e3, 1),
+                "bwd_us_median": round(bm, 2), "bwd_us_min": round(bmin, 2),
+                "bwd_GBps": round(bwd_bytes(N, S, Lq) / bm / 1e3, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
