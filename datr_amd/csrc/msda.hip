@@ -37,18 +37,13 @@ constexpr int kThreads = 256;
 constexpr unsigned kOutOfRange = 0x80000000u;   // >= num_records of every descriptor we build
 constexpr int kMaxFastLdsBytes = 64 * 1024;
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 struct LevelMeta { int H, W, start, pad; };      // 16 B in LDS
 
 __device__ __forceinline__ float4 load_row4(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
-    u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-    float4 f;
-    f.x = __builtin_bit_cast(float, r.x);
-    f.y = __builtin_bit_cast(float, r.y);
-    f.z = __builtin_bit_cast(float, r.z);
-    f.w = __builtin_bit_cast(float, r.w);
-    return f;
+    // NB: keep `auto` -- converting the builtin's result to an ext_vector typedef splats lane 0.
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    static_assert(sizeof(r) == 16, "b128 load must return 16 bytes");
+    return __builtin_bit_cast(float4, r);
 }
 
 // Sum over the LPR lanes that share one (query, head) row; every lane ends with the total.
@@ -190,8 +185,15 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_rows(
 
 // ------------------------------------------------------------------------------------------
 // Backward, fast path.  LDS per sample: {off[4]}, {lh, lw, a*W, a*H}, {a, -, -, -} = 48 B.
+//
+// Lane mapping differs from the forward on purpose.  Measured on MI355X
+// (tools/probes/atomics_probe2.hip, profiles/r01_probes.md): float atomics retire per 64-B
+// request -- 80 G atomics/s when the lanes of one row hit dwords 16 B apart (the float4
+// mapping), 326 G/s when 16 lanes hit 16 consecutive dwords.  So here 16 lanes share a row
+// and lane j owns channels j, j+16, ... (CPL = D/16 of them): every atomic instruction and
+// every load instruction of a row covers one contiguous 64-B half line.
 // ------------------------------------------------------------------------------------------
-template <int LPR, int KS>
+template <int CPL, int KS>   // CPL = D/16 channels per lane
 __global__ __launch_bounds__(kThreads) void msda_bwd_rows(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_rows(
     int P, int q_tiles, float *__restrict__ grad_value, float *__restrict__ grad_loc,
     float *__restrict__ grad_attn)
 {
-    constexpr int D = 4 * LPR;
+    constexpr int LPR = 16;
+    constexpr int D = LPR * CPL;
     constexpr int QPB = kThreads / LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = KS ? KS : L * P;
@@ -249,11 +252,12 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_rows(
         const_cast<float *>(value + item), 0, records, 0x00020000);
     __amdgpu_buffer_rsrc_t gsrc =
         __builtin_amdgcn_make_buffer_rsrc(grad_value + item, 0, records, 0x00020000);
-    const unsigned chan = (unsigned)j * 16u;
+    const unsigned chan = (unsigned)j * 4u;            // byte offset of this lane's first channel
     const char *slot = stage + row * slot_bytes;
 
-    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) go = reinterpret_cast<const float4 *>(grad_out + qm * D)[j];
+    float go[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) go[c] = live ? grad_out[qm * D + j + c * LPR] : 0.f;
 
     for (int t = 0; t < K; t += LPR) {
         float keep_w = 0.f, keep_h = 0.f, keep_a = 0.f;
@@ -266,38 +270,26 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_rows(
                 const float a = *reinterpret_cast<const float *>(slot + s * 48 + 32);
                 const float lh = g.x, lw = g.y, aW = g.z, aH = g.w;
                 const float hh = 1.f - lh, hw = 1.f - lw;
-                const float4 v0 = load_row4(vsrc, o.x + chan);
-                const float4 v1 = load_row4(vsrc, o.y + chan);
-                const float4 v2 = load_row4(vsrc, o.z + chan);
-                const float4 v3 = load_row4(vsrc, o.w + chan);
-
-                // d out / d value at the four corners (dropped by hardware when out of range)
-                const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
                 const float c0 = hh * hw, c1 = hh * lw, c2 = lh * hw, c3 = lh * lw;
-#define DATR_ATOMIC_ROW(OFF, C)                                                              \
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((C) * ga.x, gsrc, (OFF) + chan, 0, 0);  \
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((C) * ga.y, gsrc, (OFF) + chan + 4, 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((C) * ga.z, gsrc, (OFF) + chan + 8, 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((C) * ga.w, gsrc, (OFF) + chan + 12, 0, 0);
-                DATR_ATOMIC_ROW(o.x, c0)
-                DATR_ATOMIC_ROW(o.y, c1)
-                DATR_ATOMIC_ROW(o.z, c2)
-                DATR_ATOMIC_ROW(o.w, c3)
-#undef DATR_ATOMIC_ROW
-
-                // this lane's 4-channel share of the three per-sample reductions
-                float pa = go.x * (c0 * v0.x + c1 * v1.x + c2 * v2.x + c3 * v3.x) +
-                           go.y * (c0 * v0.y + c1 * v1.y + c2 * v2.y + c3 * v3.y) +
-                           go.z * (c0 * v0.z + c1 * v1.z + c2 * v2.z + c3 * v3.z) +
-                           go.w * (c0 * v0.w + c1 * v1.w + c2 * v2.w + c3 * v3.w);
-                float pw = go.x * (hh * (v1.x - v0.x) + lh * (v3.x - v2.x)) +
-                           go.y * (hh * (v1.y - v0.y) + lh * (v3.y - v2.y)) +
-                           go.z * (hh * (v1.z - v0.z) + lh * (v3.z - v2.z)) +
-                           go.w * (hh * (v1.w - v0.w) + lh * (v3.w - v2.w));
-                float ph = go.x * (hw * (v2.x - v0.x) + lw * (v3.x - v1.x)) +
-                           go.y * (hw * (v2.y - v0.y) + lw * (v3.y - v1.y)) +
-                           go.z * (hw * (v2.z - v0.z) + lw * (v3.z - v1.z)) +
-                           go.w * (hw * (v2.w - v0.w) + lw * (v3.w - v1.w));
+                float pa = 0.f, pw = 0.f, ph = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const unsigned co = chan + (unsigned)(c * LPR * 4);
+                    const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vsrc, o.x + co, 0, 0));
+                    const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vsrc, o.y + co, 0, 0));
+                    const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vsrc, o.z + co, 0, 0));
+                    const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vsrc, o.w + co, 0, 0));
+                    // d out / d value at the four corners (dropped by hardware when out of range)
+                    const float ga = go[c] * a;
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c0 * ga, gsrc, o.x + co, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c1 * ga, gsrc, o.y + co, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c2 * ga, gsrc, o.z + co, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c3 * ga, gsrc, o.w + co, 0, 0);
+                    // this lane's share of the three per-sample reductions
+                    pa += go[c] * (c0 * v0 + c1 * v1 + c2 * v2 + c3 * v3);
+                    pw += go[c] * (hh * (v1 - v0) + lh * (v3 - v2));
+                    ph += go[c] * (hw * (v2 - v0) + lw * (v3 - v1));
+                }
                 pa = row_sum<LPR>(pa);
                 pw = row_sum<LPR>(pw) * aW;
                 ph = row_sum<LPR>(ph) * aH;
@@ -479,22 +471,22 @@ int launch_fwd_rows(const float *value, const int64_t *shapes, const int64_t *ls
     return check_launch();
 }
 
-template <int LPR>
+template <int CPL>
 int launch_bwd_rows(const float *go, const float *value, const int64_t *shapes, const int64_t *ls,
                     const float *loc, const float *attn, int64_t N, int64_t S, int64_t M, int64_t L,
                     int64_t Lq, int64_t P, float *gv, float *gl, float *ga, hipStream_t st) {
-    const int qpb = kThreads / LPR;
+    const int qpb = kThreads / 16;
     const int q_tiles = (int)((Lq + qpb - 1) / qpb);
     const int64_t blocks = N * q_tiles * M;
     if (blocks > 0x7fffffff) return DATR_EUNSUPPORTED;
     const int K = (int)(L * P);
     const size_t lds = ((L * 16 + 15) & ~15) + (size_t)qpb * (K * 48 + 16);
     if (K == 16)
-        hipLaunchKernelGGL((msda_bwd_rows<LPR, 16>), dim3((unsigned)blocks), dim3(kThreads), lds, st,
+        hipLaunchKernelGGL((msda_bwd_rows<CPL, 16>), dim3((unsigned)blocks), dim3(kThreads), lds, st,
                            go, value, shapes, ls, loc, attn, (int)S, (int)M, (int)L, (int)Lq, (int)P,
                            q_tiles, gv, gl, ga);
     else
-        hipLaunchKernelGGL((msda_bwd_rows<LPR, 0>), dim3((unsigned)blocks), dim3(kThreads), lds, st,
+        hipLaunchKernelGGL((msda_bwd_rows<CPL, 0>), dim3((unsigned)blocks), dim3(kThreads), lds, st,
                            go, value, shapes, ls, loc, attn, (int)S, (int)M, (int)L, (int)Lq, (int)P,
                            q_tiles, gv, gl, ga);
     return check_launch();
@@ -585,9 +577,9 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
     if (!grad_out || !shapes || !level_start || !loc || !attn || !grad_loc || !grad_attn)
         return DATR_EINVAL;
     switch (fast_lpr(S, M, D, L, P, 48)) {
-        case 4: return launch_bwd_rows<4>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn, st);
-        case 8: return launch_bwd_rows<8>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn, st);
-        case 16: return launch_bwd_rows<16>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn, st);
+        case 4: return launch_bwd_rows<1>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn, st);
+        case 8: return launch_bwd_rows<2>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn, st);
+        case 16: return launch_bwd_rows<4>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn, st);
         default: return backward_generic<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, st);
     }
 }

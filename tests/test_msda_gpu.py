@@ -49,6 +49,17 @@ def load(golden_dir, name):
     return {k: torch.from_numpy(z[k]) for k in z.files}
 
 
+def off_grid(loc, shapes, eps=1e-3):
+    """Mask [N,Lq,M,L,P,2] of samples whose pixel coordinates are at least `eps` away from an
+    integer: d/d(loc) is discontinuous on grid lines, and two float pipelines (fp32 vs fp64,
+    fused vs unfused multiply-add) may floor to different sides there."""
+    HW = shapes.to(torch.float64).to(loc.device)
+    h_im = loc[..., 1].double() * HW[:, 0].view(1, 1, 1, -1, 1) - 0.5
+    w_im = loc[..., 0].double() * HW[:, 1].view(1, 1, 1, -1, 1) - 0.5
+    near = ((h_im - h_im.round()).abs() < eps) | ((w_im - w_im.round()).abs() < eps)
+    return (~near).unsqueeze(-1).expand(*loc.shape)
+
+
 def run_hip(M, dev, value, shapes, lsi, loc, attn, grad_out=None):
     v, s, a = value.to(dev), loc.to(dev), attn.to(dev)
     sh, ls = shapes.to(dev), lsi.to(dev)
@@ -106,7 +117,8 @@ def test_matches_c_oracle(M, O, dev, case):
     rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
     torch.testing.assert_close(gv, rv, **tol(dtype, 10))
     torch.testing.assert_close(ga, ra, **tol(dtype, 10))
-    torch.testing.assert_close(gl, rl, **tol(dtype, 100))
+    keep = off_grid(loc, sh, eps=1e-4)
+    torch.testing.assert_close(gl[keep], rl[keep], **tol(dtype, 100))
 
 
 def test_empty_and_fully_out_of_range(M, O, dev):
@@ -217,13 +229,17 @@ def test_full_size_properties(M, O, dev, Lq):
     # grad_loc / grad_attn use no atomics -> bitwise reproducible; grad_value to rounding
     gv2, gl2, ga2 = M.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
     assert torch.equal(gl, gl2) and torch.equal(ga, ga2)
-    torch.testing.assert_close(gv, gv2, rtol=1e-3, atol=1e-6)
+    scale = float(gv.abs().max())         # hot pixels sum thousands of atomically-added terms
+    torch.testing.assert_close(gv, gv2, rtol=1e-3, atol=1e-5 * scale)
     # backward against the fp64 generic kernels
     gv64, gl64, ga64 = M.ms_deform_attn_backward(value.double(), sh, lsi, loc.double(),
                                                  attn.double(), go.double(), 64)
-    torch.testing.assert_close(gv.double(), gv64, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(gv.double(), gv64, rtol=1e-3, atol=1e-5 * scale)
     torch.testing.assert_close(ga.double(), ga64, rtol=1e-3, atol=1e-6)
-    torch.testing.assert_close(gl.double(), gl64, rtol=1e-3, atol=1e-4)
+    # d/d(loc) jumps where a pixel coordinate crosses an integer; fp32 and fp64 can floor to
+    # different sides there, so leave out samples within 1e-3 px of a grid line
+    keep = off_grid(loc, sh)
+    torch.testing.assert_close(gl.double()[keep], gl64[keep], rtol=1e-3, atol=1e-4)
 
 
 def test_full_size_subsample_against_oracle(M, O, dev):
@@ -234,6 +250,8 @@ def test_full_size_subsample_against_oracle(M, O, dev):
     out, gv, gl, ga = run_hip(M, dev, value, sh, lsi, loc, attn, go)
     torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
     rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
-    torch.testing.assert_close(gv, rv, **tol(torch.float32, 10))
+    scale = float(rv.abs().max())
+    torch.testing.assert_close(gv, rv, rtol=1e-3, atol=1e-5 * scale)
     torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
-    torch.testing.assert_close(gl, rl, **tol(torch.float32, 100))
+    keep = off_grid(loc, sh)
+    torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
