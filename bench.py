@@ -1,0 +1,248 @@
+"""bench.py -- headline benchmark of the DATR hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 8 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = the body of the reference's training loop (/root/reference/engine.py:54-111) on
+one synthetic batch: model(samples, targets) -> criterion -> sum(loss*weight) -> zero_grad ->
+backward -> gradient all-reduce -> clip_grad_norm_(0.1) -> AdamW step, for DINO-4scale R50 with
+DATR's domain-adaptation branch (the reference has no switch that turns it off while training,
+SURVEY.md 8d), batch_size 2 per GPU = 2 source + 2 target images of 1333x800, fp32.
+Inputs are resident in HBM before the timed region.  Weak scaling: every rank runs the same
+per-GPU batch; value = images of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line: the driver's contract fields plus
+  roofline     -- MSDA forward (encoder call, the dominant HIP kernel family of this repo):
+                  algorithmic bytes / mean launch duration measured with HIP
+                  events on the launch stream inside the timed region, vs 8 TB/s HBM
+  cpu_baseline -- the same training step on the host cores (PyTorch-CPU + oracle/msda_ref.c,
+                  the counterpart of the reference's CPU fallback) on a bounded sample:
+                  ONE step at 640x640, B=1 (BASELINE config 1's shape), N=1 runs only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synthetic_batch(batch_size, height, width, num_gt, device, seed):
+    """images randn [2B,3,H,W] (already 'normalised'), no padding; per source
+    image `num_gt` boxes, labels in 1..8, cxcy ~ U(0.2,0.8), wh ~ U(0.05,0.25)."""
+    from datr_amd.nested import NestedTensor
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randn(2 * batch_size, 3, height, width, generator=g)
+    mask = torch.zeros(2 * batch_size, height, width, dtype=torch.bool)
+    targets = []
+    for _ in range(batch_size):
+        cxcy = torch.rand(num_gt, 2, generator=g) * 0.6 + 0.2
+        wh = torch.rand(num_gt, 2, generator=g) * 0.2 + 0.05
+        targets.append({"boxes": torch.cat([cxcy, wh], 1).to(device),
+                        "labels": torch.randint(1, 9, (num_gt,), generator=g).to(device)})
+    return NestedTensor(imgs.to(device), mask.to(device)), targets
+
+
+class Trainer:
+    """The per-step sequence of engine.train_one_epoch, with gradients living in the flat
+    buckets of datr_amd.dist.GradAllReducer."""
+
+    def __init__(self, args, device, distributed):
+        from datr_amd.config import c2f_args, get_param_dict
+        from datr_amd.detector import build_dino
+        from datr_amd.dist import GradAllReducer
+        self.cfg = c2f_args(device=str(device))
+        torch.manual_seed(0)
+        self.model, self.criterion, _ = build_dino(self.cfg)
+        self.model.to(device)
+        self.model.train()
+        self.criterion.train()
+        self.optimizer = torch.optim.AdamW(get_param_dict(self.cfg, self.model), lr=self.cfg.lr,
+                                           weight_decay=self.cfg.weight_decay)
+        self.reducer = GradAllReducer(self.model) if distributed or args.flat_grads else None
+        self.max_norm = self.cfg.clip_max_norm
+
+    def step(self, samples, targets):
+        out = self.model(samples, targets)
+        loss_dict = self.criterion(out, targets)
+        wd = self.criterion.weight_dict
+        loss = sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.optimizer.zero_grad()
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
+        self.optimizer.step()
+        return loss
+
+
+class MsdaTimer:
+    """Brackets every MSDA forward launch whose Lq equals S (the encoder calls) with HIP
+    events on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        from datr_amd import msda
+        self.msda = msda
+        self.orig = msda.ms_deform_attn_forward
+        self.events = []
+        self.shape = None
+        self.enabled = False
+
+    def install(self):
+        def timed(value, shapes, lsi, loc, attn, step):
+            if self.enabled and loc.shape[1] == value.shape[1]:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                out = self.orig(value, shapes, lsi, loc, attn, step)
+                b.record()
+                self.events.append((a, b))
+                self.shape = (value.shape[0], value.shape[1], value.shape[2], value.shape[3],
+                              loc.shape[3] * loc.shape[4], loc.shape[1])
+                return out
+            return self.orig(value, shapes, lsi, loc, attn, step)
+        self.msda.ms_deform_attn_forward = timed
+
+    def result(self):
+        if not self.events:
+            return None
+        us = [a.elapsed_time(b) * 1e3 for a, b in self.events]
+        N, S, M, D, K, Lq = self.shape
+        algo_bytes = 4 * N * (S * M * D + Lq * M * K * 3 + Lq * M * D)
+        mean_us = sum(us) / len(us)
+        achieved = algo_bytes / mean_us / 1e3
+        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": "msda_fwd_rows<8,16> (encoder call)", "launches": len(us),
+                "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
+
+
+def cpu_baseline():
+    """Reference-equivalent CPU step (torch CPU kernels + the C oracle for MSDA) on the host
+    cores: ONE training step at 640x640, B=1 (2 images), after one un-timed build."""
+    from datr_amd import msda
+    from datr_amd.config import c2f_args, get_param_dict
+    from datr_amd.detector import build_dino
+    from oracle import msda_oracle as O
+
+    def fwd(value, shapes, lsi, loc, attn, step):
+        return O.msda_forward(value, shapes, lsi, loc, attn)
+
+    def bwd(value, shapes, lsi, loc, attn, go, step):
+        return list(O.msda_backward(value, shapes, lsi, loc, attn, go))
+
+    saved = (msda.ms_deform_attn_forward, msda.ms_deform_attn_backward)
+    msda.ms_deform_attn_forward, msda.ms_deform_attn_backward = fwd, bwd
+    try:
+        cfg = c2f_args(device="cpu")
+        torch.manual_seed(0)
+        model, criterion, _ = build_dino(cfg)
+        model.train()
+        criterion.train()
+        opt = torch.optim.AdamW(get_param_dict(cfg, model), lr=cfg.lr, weight_decay=cfg.weight_decay)
+        samples, targets = synthetic_batch(1, 640, 640, 5, torch.device("cpu"), seed=1)
+        t0 = time.perf_counter()
+        out = model(samples, targets)
+        loss_dict = criterion(out, targets)
+        wd = criterion.weight_dict
+        loss = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.clip_max_norm)
+        opt.step()
+        dt = time.perf_counter() - t0
+    finally:
+        msda.ms_deform_attn_forward, msda.ms_deform_attn_backward = saved
+    return {"value": round(2.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"1 training step, 1 source + 1 target image 640x640 (BASELINE config 1 "
+                      f"shape), {dt:.1f} s on {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="reference batch_size per GPU (image pairs)")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--num-gt", type=int, default=10)
+    ap.add_argument("--flat-grads", action="store_true", help="use the flat-bucket reducer at N=1 too")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from datr_amd.dist import init_distributed
+    rank, local_rank, world = init_distributed()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    trainer = Trainer(args, device, distributed=world > 1)
+    samples, targets = synthetic_batch(args.batch, args.height, args.width, args.num_gt, device,
+                                       seed=1 + rank)
+    timer = MsdaTimer()
+    timer.install()
+
+    for _ in range(args.warmup):
+        trainer.step(samples, targets)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(samples, targets)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        images = 2 * args.batch * world * args.steps
+        line = {
+            "metric": "images/sec, DINO-4scale R50 + DATR DA branch training step, bs=2/GPU, 1333x800",
+            "value": round(images / elapsed, 3), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "DINO-4scale R50 bs=2 1333x800 burn-in step (fwd + SetCriterion "
+                                   "+ bwd + clip + AdamW; source+target pass, D_img, prototypes)",
+                       "images_per_gpu": 2 * args.batch, "global_batch_pairs": args.batch * world,
+                       "parallelism": f"dp{world}", "num_gt_per_image": args.num_gt},
+            "pairs_per_sec": round(images / elapsed / 2, 3),
+            "roofline": timer.result(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+"""ResNet-50 backbone with frozen batch-norm, padding masks and sine position encoding.
+
+Mirror of /root/reference/models/dino/backbone.py (`FrozenBatchNorm2d` :36-72, `BackboneBase`
+:75-106, `Backbone` :109-128, `Joiner` :131-144, `build_backbone` :147-219) and of
+/root/reference/models/dino/position_encoding.py (`PositionEmbeddingSineHW` :62-108).
+
+The ResNet-50 arithmetic itself is NOT in the reference tree: it comes from torchvision
+(`torchvision.models.resnet50`, requirements.txt:5, un-vendored).  `ResNet50Body` restates the
+public v1.5 architecture (stride on the 3x3 conv of each bottleneck) with torchvision's
+parameter names so that DATR / DINO checkpoints load unchanged
+(`backbone.0.body.layerK.J.{conv,bn}N.*`).  Parity for it is unpinned by any
+reference test; tests/test_backbone.py pins shapes, names and the frozen-BN algebra.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .nested import NestedTensor
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """y = x * w/sqrt(var+eps) + (b - mean * w/sqrt(var+eps)); statistics and affine are
+    buffers (never trained), eps = 1e-5 inside the rsqrt (backbone.py:62-72)."""
+
+    def __init__(self, n: int):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        state_dict.pop(prefix + "num_batches_tracked", None)   # torchvision BN checkpoints
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + 1e-5).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int, norm_layer, downsample: bool):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = norm_layer(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                norm_layer(planes * 4))
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+class ResNet50Body(nn.Module):
+    """conv1 / bn1 / relu / maxpool / layer1..4 with torchvision's child names and order."""
+
+    def __init__(self, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or FrozenBatchNorm2d
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        inplanes = 64
+        for idx, (planes, blocks, stride) in enumerate(
+                [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], start=1):
+            layers = [Bottleneck(inplanes, planes, stride, norm_layer, downsample=True)]
+            inplanes = planes * 4
+            layers += [Bottleneck(inplanes, planes, 1, norm_layer, downsample=False)
+                       for _ in range(blocks - 1)]
+            setattr(self, f"layer{idx}", nn.Sequential(*layers))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):                      # plain classifier-less trunk
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        for i in range(1, 5):
+            x = getattr(self, f"layer{i}")(x)
+        return x
+
+
+class _StageOutputs(nn.ModuleDict):
+    """Runs the trunk's children in order and returns the requested stages
+    (the role torchvision's IntermediateLayerGetter plays in backbone.py:96)."""
+
+    def __init__(self, trunk: nn.Module, return_layers: Dict[str, str]):
+        wanted = dict(return_layers)
+        kept = OrderedDict()
+        for name, child in trunk.named_children():
+            kept[name] = child
+            wanted.pop(name, None)
+            if not wanted:
+                break
+        super().__init__(kept)
+        self.return_layers = dict(return_layers)
+
+    def forward(self, x):
+        out = OrderedDict()
+        for name, child in self.items():
+            x = child(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+class Backbone(nn.Module):
+    """ResNet-50 trunk; conv1/bn1/layer1 frozen, layer2-4 trainable (backbone.py:79-81);
+    returns {name: NestedTensor(feature, nearest-resized padding mask)}."""
+
+    def __init__(self, name: str, train_backbone: bool, dilation: bool,
+                 return_interm_indices: List[int], batch_norm=FrozenBatchNorm2d):
+        super().__init__()
+        if name != "resnet50":
+            raise NotImplementedError(f"only resnet50 is on the hot path, got {name}")
+        if dilation:
+            raise NotImplementedError("dilation=False in every DA config")
+        assert return_interm_indices in [[0, 1, 2, 3], [1, 2, 3], [3]]
+        trunk = ResNet50Body(norm_layer=batch_norm)
+        for pname, p in trunk.named_parameters():
+            if not train_backbone or not any(k in pname for k in ("layer2", "layer3", "layer4")):
+                p.requires_grad_(False)
+        n = len(return_interm_indices)
+        return_layers = {f"layer{5 - n + i}": str(idx) for i, idx in enumerate(return_interm_indices)}
+        self.body = _StageOutputs(trunk, return_layers)
+        self.num_channels = [256, 512, 1024, 2048][4 - n:]
+
+    def forward(self, tensor_list: NestedTensor):
+        feats = self.body(tensor_list.tensors)
+        out: Dict[str, NestedTensor] = {}
+        m = tensor_list.mask
+        assert m is not None
+        for name, x in feats.items():
+            mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
+            out[name] = NestedTensor(x, mask)
+        return out
+
+
+class PositionEmbeddingSineHW(nn.Module):
+    """Sine/cosine embedding of the cumulative (unpadded) row / column index, normalised to
+    [0, 2*pi], with separate temperatures for y and x; output [N, 2*num_pos_feats, H, W] with
+    the y half first (position_encoding.py:79-108)."""
+
+    def __init__(self, num_pos_feats=64, temperatureH=10000, temperatureW=10000, normalize=False,
+                 scale=None):
+        super().__init__()
+        if scale is not None and not normalize:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats = num_pos_feats
+        self.temperatureH, self.temperatureW = temperatureH, temperatureW
+        self.normalize = normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, tensor_list: NestedTensor):
+        x, mask = tensor_list.tensors, tensor_list.mask
+        assert mask is not None
+        valid = ~mask
+        y_embed = valid.cumsum(1, dtype=torch.float32)
+        x_embed = valid.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            eps = 1e-6
+            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
+            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
+        k = torch.arange(self.num_pos_feats, dtype=torch.float32, device=x.device)
+        expo = 2 * torch.div(k, 2, rounding_mode="floor") / self.num_pos_feats
+        px = x_embed[:, :, :, None] / (self.temperatureW ** expo)
+        py = y_embed[:, :, :, None] / (self.temperatureH ** expo)
+        px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+        py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)
+
+
+class Joiner(nn.Sequential):
+    """[0] = Backbone, [1] = position embedding (state_dict prefix `backbone.0.body...`)."""
+
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+
+    def forward(self, tensor_list: NestedTensor):
+        feats = self[0](tensor_list)
+        out: List[NestedTensor] = []
+        pos = []
+        for _, x in feats.items():
+            out.append(x)
+            pos.append(self[1](x).to(x.tensors.dtype))
+        return out, pos
+
+
+def build_position_encoding(args):
+    if args.position_embedding not in ("v2", "sine"):
+        raise ValueError(f"not supported {args.position_embedding}")
+    return PositionEmbeddingSineHW(args.hidden_dim // 2, temperatureH=args.pe_temperatureH,
+                                   temperatureW=args.pe_temperatureW, normalize=True)
+
+
+def build_backbone(args):
+    position_embedding = build_position_encoding(args)
+    if not args.lr_backbone > 0:
+        raise ValueError("Please set lr_backbone > 0")
+    if args.backbone not in ("resnet50",):
+        raise NotImplementedError(f"Unknown backbone {args.backbone}")
+    backbone = Backbone(args.backbone, True, args.dilation, args.return_interm_indices,
+                        batch_norm=FrozenBatchNorm2d)
+    model = Joiner(backbone, position_embedding)
+    model.num_channels = backbone.num_channels
+    return model

@@ -1,0 +1,46 @@
+"""Box utilities on the hot path (mirror of /root/reference/util/box_ops.py:9-63).
+
+Quirks kept on purpose: `box_iou` adds 1e-6 to the union and `generalized_box_iou` adds 1e-6
+to the hull area (box_ops.py:37,63); degenerate boxes assert (box_ops.py:52-53).
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+
+def box_cxcywh_to_xyxy(x: Tensor) -> Tensor:
+    cx, cy, w, h = x.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+def box_xyxy_to_cxcywh(x: Tensor) -> Tensor:
+    x0, y0, x1, y1 = x.unbind(-1)
+    return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], dim=-1)
+
+
+def box_area(boxes: Tensor) -> Tensor:
+    return (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+
+
+def box_iou(boxes1: Tensor, boxes2: Tensor):
+    """Pairwise IoU [N,M] and union [N,M] of xyxy boxes."""
+    area1, area2 = box_area(boxes1), box_area(boxes2)
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    union = area1[:, None] + area2 - inter
+    return inter / (union + 1e-6), union
+
+
+def generalized_box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """Pairwise GIoU [N,M] of xyxy boxes."""
+    assert (boxes1[:, 2:] >= boxes1[:, :2]).all()
+    assert (boxes2[:, 2:] >= boxes2[:, :2]).all()
+    iou, union = box_iou(boxes1, boxes2)
+    lt = torch.min(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.max(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    hull = wh[:, :, 0] * wh[:, :, 1]
+    return iou - (hull - union) / (hull + 1e-6)

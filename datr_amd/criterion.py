@@ -1,0 +1,261 @@
+"""Training criterion of DATR/DINO: Hungarian-matched focal / L1 / GIoU losses for the final,
+auxiliary, two-stage and de-noising outputs, plus the three domain-adaptation losses.
+
+Mirror of /root/reference/models/dino/dino.py `SetCriterion` (:486-941) and of
+/root/reference/models/dino/utils.py `sigmoid_focal_loss` (:79-104).  Loss-dict keys, their
+order of creation and every normaliser follow the reference:
+  * focal:  sum over queries of the per-query class mean, / num_boxes, * num_queries;
+  * DN:     analytic indices, normaliser num_boxes * num_dn_groups;
+  * num_boxes = clamp(all_reduce(sum T_i) / world, min = 1);
+  * loss_da: mean BCE on source tokens (label 0) + mean BCE on target tokens (label 1);
+  * loss_proto_da: BCE masked by class presence but averaged over all 2C entries;
+  * loss_contrast_da: cross-entropy with soft (masked identity) targets on cosine logits.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from . import boxes as box_ops
+from .nested import accuracy, get_world_size, is_dist_avail_and_initialized
+
+
+def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: float = 2):
+    prob = inputs.sigmoid()
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean(1).sum() / num_boxes
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses):
+        super().__init__()
+        self.num_classes = num_classes
+        self.matcher = matcher
+        self.weight_dict = weight_dict
+        self.losses = losses
+        self.focal_alpha = focal_alpha
+
+    # ---- matched losses ---------------------------------------------------------------------
+    def loss_labels(self, outputs, targets, indices, num_boxes, log=True):
+        src_logits = outputs["pred_logits"]
+        idx = self._get_src_permutation_idx(indices)
+        matched_cls = torch.cat([t["labels"][J] for t, (_, J) in zip(targets, indices)])
+        target_classes = torch.full(src_logits.shape[:2], self.num_classes, dtype=torch.int64,
+                                    device=src_logits.device)
+        target_classes[idx] = matched_cls
+        onehot = torch.zeros([src_logits.shape[0], src_logits.shape[1], src_logits.shape[2] + 1],
+                             dtype=src_logits.dtype, device=src_logits.device)
+        onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
+        onehot = onehot[:, :, :-1]
+        loss_ce = sigmoid_focal_loss(src_logits, onehot, num_boxes, alpha=self.focal_alpha,
+                                     gamma=2) * src_logits.shape[1]
+        losses = {"loss_ce": loss_ce}
+        if log:
+            losses["class_error"] = 100 - accuracy(src_logits[idx], matched_cls)[0]
+        return losses
+
+    @torch.no_grad()
+    def loss_cardinality(self, outputs, targets, indices, num_boxes):
+        logits = outputs["pred_logits"]
+        tgt_lengths = torch.as_tensor([len(v["labels"]) for v in targets], device=logits.device)
+        card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
+        return {"cardinality_error": F.l1_loss(card_pred.float(), tgt_lengths.float())}
+
+    def loss_boxes(self, outputs, targets, indices, num_boxes):
+        idx = self._get_src_permutation_idx(indices)
+        src_boxes = outputs["pred_boxes"][idx]
+        target_boxes = torch.cat([t["boxes"][i] for t, (_, i) in zip(targets, indices)], dim=0)
+        l1 = F.l1_loss(src_boxes, target_boxes, reduction="none")
+        losses = {"loss_bbox": l1.sum() / num_boxes}
+        giou = torch.diag(box_ops.generalized_box_iou(box_ops.box_cxcywh_to_xyxy(src_boxes),
+                                                      box_ops.box_cxcywh_to_xyxy(target_boxes)))
+        losses["loss_giou"] = (1 - giou).sum() / num_boxes
+        with torch.no_grad():
+            losses["loss_xy"] = l1[..., :2].sum() / num_boxes
+            losses["loss_hw"] = l1[..., 2:].sum() / num_boxes
+        return losses
+
+    @staticmethod
+    def _get_src_permutation_idx(indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        src_idx = torch.cat([src for (src, _) in indices])
+        return batch_idx, src_idx
+
+    @staticmethod
+    def _get_tgt_permutation_idx(indices):
+        batch_idx = torch.cat([torch.full_like(tgt, i) for i, (_, tgt) in enumerate(indices)])
+        tgt_idx = torch.cat([tgt for (_, tgt) in indices])
+        return batch_idx, tgt_idx
+
+    def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
+        table = {"labels": self.loss_labels, "cardinality": self.loss_cardinality,
+                 "boxes": self.loss_boxes}
+        assert loss in table, f"do you really want to compute {loss} loss?"
+        return table[loss](outputs, targets, indices, num_boxes, **kwargs)
+
+    # ---- domain-adaptation losses -----------------------------------------------------------
+    def loss_da(self, outputs):
+        B = outputs.shape[0]
+        assert B % 2 == 0
+        src, tgt = outputs[:B // 2], outputs[B // 2:]
+        return (F.binary_cross_entropy_with_logits(src, torch.zeros_like(src))
+                + F.binary_cross_entropy_with_logits(tgt, torch.ones_like(tgt)))
+
+    def loss_proto_da(self, outputs):
+        protos = outputs["da_protos"]
+        assert protos.shape[0] % 2 == 0
+        cm_s, cm_t = outputs["class_map_source"], outputs["class_map_target"]
+        C = cm_s.shape[0]
+        domain = torch.empty_like(protos)
+        domain[:C] = 0
+        domain[C:] = 1
+        loss = F.binary_cross_entropy_with_logits(protos, domain, reduction="none")
+        return (loss * torch.cat([cm_s, cm_t], dim=0).unsqueeze(1)).mean()
+
+    def loss_contrast_da(self, outputs):
+        q_s, q_t = outputs["output_source"], outputs["outputs_target"]
+        m_s, m_t = outputs["query_mask_source"], outputs["query_mask_target"]
+        g = outputs["global_proto"]
+        assert not g.requires_grad and not m_s.requires_grad and not m_t.requires_grad
+        assert q_s.requires_grad and q_t.requires_grad
+        C = q_s.shape[0]
+        g = F.normalize(g, dim=1).permute(1, 0).contiguous()
+        logits_s = F.normalize(q_s, dim=1).mm(g)
+        logits_t = F.normalize(q_t, dim=1).mm(g)
+        eye = torch.eye(C, device=logits_s.device)
+        ce = nn.CrossEntropyLoss()
+        return ce(logits_s, eye * m_s) + ce(logits_t, eye * m_t)
+
+    # ---- orchestration ----------------------------------------------------------------------
+    def _dn_indices(self, targets, single_pad, groups, device):
+        pos, neg = [], []
+        for t in targets:
+            n = len(t["labels"])
+            if n > 0:
+                tgt_idx = torch.arange(n, device=device).unsqueeze(0).repeat(groups, 1)
+                out_idx = (torch.arange(groups, device=device) * single_pad).unsqueeze(1) + tgt_idx
+                tgt_idx, out_idx = tgt_idx.flatten(), out_idx.flatten()
+            else:
+                out_idx = tgt_idx = torch.tensor([], dtype=torch.long, device=device)
+            pos.append((out_idx, tgt_idx))
+            neg.append((out_idx + single_pad // 2, tgt_idx))
+        return pos, neg
+
+    def _zero_dn(self, device, suffix=""):
+        z = lambda: torch.as_tensor(0.0, device=device)
+        return {k + suffix: z() for k in ("loss_bbox_dn", "loss_giou_dn", "loss_ce_dn", "loss_xy_dn",
+                                          "loss_hw_dn", "cardinality_error_dn")}
+
+    def forward(self, outputs, targets, return_indices=False, target_domain_flag=False):
+        if target_domain_flag:
+            outputs_without_aux = {k.replace("_target", ""): v for k, v in outputs.items()
+                                   if k != "aux_outputs_target"}
+            outputs.update({"pred_boxes": outputs.pop("pred_boxes_target")})
+            outputs.update({"pred_logits": outputs.pop("pred_logits_target")})
+            device = outputs["pred_logits"].device
+        else:
+            outputs_without_aux = {k: v for k, v in outputs.items() if k != "aux_outputs"}
+            device = next(iter(outputs.values())).device
+
+        if len(targets) > 0:
+            indices = self.matcher(outputs_without_aux, targets)
+            num_boxes = float(sum(len(t["labels"]) for t in targets))
+            if return_indices:
+                indices0_copy, indices_list = indices, []
+        else:           # no pseudo labels on this rank: keep the collective below in lock-step
+            indices, num_boxes = None, 1.0
+
+        if is_dist_avail_and_initialized():
+            nb = torch.as_tensor([num_boxes], dtype=torch.float, device=device)
+            dist.all_reduce(nb)
+            if indices is None:
+                nb = nb - 1
+            num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]   # stays on device: no sync
+        else:
+            if indices is None:
+                num_boxes -= 1
+            num_boxes = max(num_boxes / get_world_size(), 1.0)
+        if indices is None:
+            return {}
+
+        losses = {}
+        if not target_domain_flag:
+            dn_meta = outputs["dn_meta"]
+            use_dn = bool(self.training and dn_meta and "output_known_lbs_bboxes" in dn_meta)
+            if use_dn:
+                known = dn_meta["output_known_lbs_bboxes"]
+                groups, pad_size = dn_meta["num_dn_group"], dn_meta["pad_size"]
+                assert pad_size % groups == 0
+                single_pad = pad_size // groups
+                dn_pos_idx, _ = self._dn_indices(targets, single_pad, groups, device)
+                l_dict = {}
+                for loss in self.losses:
+                    kwargs = {"log": False} if "labels" in loss else {}
+                    l_dict.update(self.get_loss(loss, known, targets, dn_pos_idx,
+                                                num_boxes * groups, **kwargs))
+                losses.update({k + "_dn": v for k, v in l_dict.items()})
+            else:
+                losses.update(self._zero_dn(device))
+            for loss in self.losses:
+                losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
+
+        key_aux = "aux_outputs_target" if target_domain_flag else "aux_outputs"
+        if key_aux in outputs:
+            for idx, aux_outputs in enumerate(outputs[key_aux]):
+                indices = self.matcher(aux_outputs, targets)
+                if return_indices:
+                    indices_list.append(indices)
+                for loss in self.losses:
+                    kwargs = {"log": False} if loss == "labels" else {}
+                    l_dict = self.get_loss(loss, aux_outputs, targets, indices, num_boxes, **kwargs)
+                    losses.update({k + f"_{idx}": v for k, v in l_dict.items()})
+                if not target_domain_flag:
+                    if use_dn:
+                        aux_known = known["aux_outputs"][idx]
+                        l_dict = {}
+                        for loss in self.losses:
+                            kwargs = {"log": False} if "labels" in loss else {}
+                            l_dict.update(self.get_loss(loss, aux_known, targets, dn_pos_idx,
+                                                        num_boxes * groups, **kwargs))
+                        losses.update({k + f"_dn_{idx}": v for k, v in l_dict.items()})
+                    else:
+                        losses.update(self._zero_dn(device, f"_{idx}"))
+
+        key_interm = "interm_outputs_target" if target_domain_flag else "interm_outputs"
+        if key_interm in outputs:
+            interm = outputs[key_interm]
+            indices = self.matcher(interm, targets)
+            if return_indices:
+                indices_list.append(indices)
+            for loss in self.losses:
+                kwargs = {"log": False} if loss == "labels" else {}
+                l_dict = self.get_loss(loss, interm, targets, indices, num_boxes, **kwargs)
+                losses.update({k + "_interm": v for k, v in l_dict.items()})
+
+        key_enc = "enc_outputs_target" if target_domain_flag else "enc_outputs"
+        if key_enc in outputs:
+            for i, enc_outputs in enumerate(outputs[key_enc]):
+                indices = self.matcher(enc_outputs, targets)
+                if return_indices:
+                    indices_list.append(indices)
+                for loss in self.losses:
+                    kwargs = {"log": False} if loss == "labels" else {}
+                    l_dict = self.get_loss(loss, enc_outputs, targets, indices, num_boxes, **kwargs)
+                    losses.update({k + f"_enc_{i}": v for k, v in l_dict.items()})
+
+        if "da_output" in outputs:
+            da = outputs["da_output"]
+            losses["loss_backbone_DA"] = self.loss_da(da["backbone_DA"])
+            losses["loss_proto_DA"] = self.loss_proto_da(da["proto_DA"])
+            losses["loss_global_proto_DA"] = self.loss_contrast_da(da["global_proto_DA"])
+
+        if return_indices:
+            indices_list.append(indices0_copy)
+            return losses, indices_list
+        return losses

@@ -1,0 +1,509 @@
+"""Deformable transformer of DINO: 6 MSDA encoder layers, two-stage query selection,
+6 decoder layers with iterative box refinement.
+
+Mirror of /root/reference/models/dino/deformable_transformer.py (`DeformableTransformer`
+:25-426, `TransformerEncoder` :434-577, `TransformerDecoder` :579-763, encoder/decoder
+layers :765-994, `build_deformable_transformer` :1004-1068) and the helpers of
+/root/reference/models/dino/utils.py (`gen_encoder_output_proposals` :15-61, `MLP` :107-119,
+`gen_sineembed_for_position` :138-163).  Only the options the DA configs use are
+implemented (deformable encoder+decoder, two_stage_type 'standard' or 'no', decoder
+self-attention 'sa', module order sa -> ca -> ffn); anything else raises at build time.
+Module / parameter names equal the reference's so state_dicts interchange.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .msda import MSDeformAttn
+from .nested import inverse_sigmoid
+
+
+class MLP(nn.Module):
+    """Linear -> ReLU -> ... -> Linear (no activation after the last layer)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+def _activation(name: str):
+    table = {"relu": F.relu, "gelu": F.gelu, "glu": F.glu, "selu": F.selu}
+    if name not in table:
+        raise RuntimeError(f"activation should be relu/gelu, not {name}.")
+    return table[name]
+
+
+def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
+    """[nq, bs, 2|4] normalised (x, y[, w, h]) -> [nq, bs, 128 * last_dim] sine embedding in
+    the order (y, x[, w, h]); temperature 10000, 128 features per coordinate."""
+    k = torch.arange(128, dtype=torch.float32, device=pos_tensor.device)
+    dim_t = 10000 ** (2 * torch.div(k, 2, rounding_mode="floor") / 128)
+
+    def embed(coord):
+        p = (coord * (2 * math.pi))[:, :, None] / dim_t
+        return torch.stack((p[:, :, 0::2].sin(), p[:, :, 1::2].cos()), dim=3).flatten(2)
+
+    parts = [embed(pos_tensor[:, :, 1]), embed(pos_tensor[:, :, 0])]
+    if pos_tensor.size(-1) == 4:
+        parts += [embed(pos_tensor[:, :, 2]), embed(pos_tensor[:, :, 3])]
+    elif pos_tensor.size(-1) != 2:
+        raise ValueError(f"Unknown pos_tensor shape(-1):{pos_tensor.size(-1)}")
+    return torch.cat(parts, dim=2)
+
+
+def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor,
+                                 spatial_shapes, learnedwh=None):
+    """One anchor per encoder token: centre = pixel centre / valid extent, size 0.05 * 2^level;
+    anchors outside (0.01, 0.99) or on padding become +inf in logit space and their memory is
+    zeroed.  `spatial_shapes` is a list of (H, W) python ints or an int64 tensor."""
+    N = memory.shape[0]
+    shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist()
+              if isinstance(spatial_shapes, Tensor) else spatial_shapes)]
+    proposals = []
+    cur = 0
+    for lvl, (H, W) in enumerate(shapes):
+        m = memory_padding_mask[:, cur:cur + H * W].view(N, H, W, 1)
+        valid_H = torch.sum(~m[:, :, 0, 0], 1)
+        valid_W = torch.sum(~m[:, 0, :, 0], 1)
+        gy, gx = torch.meshgrid(
+            torch.linspace(0, H - 1, H, dtype=torch.float32, device=memory.device),
+            torch.linspace(0, W - 1, W, dtype=torch.float32, device=memory.device),
+            indexing="ij")
+        grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
+        scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N, 1, 1, 2)
+        grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
+        if learnedwh is not None:
+            wh = torch.ones_like(grid) * learnedwh.sigmoid() * (2.0 ** lvl)
+        else:
+            wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+        proposals.append(torch.cat((grid, wh), -1).view(N, -1, 4))
+        cur += H * W
+    output_proposals = torch.cat(proposals, 1)
+    ok = ((output_proposals > 0.01) & (output_proposals < 0.99)).all(-1, keepdim=True)
+    output_proposals = torch.log(output_proposals / (1 - output_proposals))
+    output_proposals = output_proposals.masked_fill(memory_padding_mask.unsqueeze(-1), float("inf"))
+    output_proposals = output_proposals.masked_fill(~ok, float("inf"))
+    output_memory = memory.masked_fill(memory_padding_mask.unsqueeze(-1), 0.0)
+    output_memory = output_memory.masked_fill(~ok, 0.0)
+    return output_memory, output_proposals
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4,
+                 n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
+                key_padding_mask=None):
+        q = src if pos is None else src + pos
+        src = self.norm1(src + self.dropout1(
+            self.self_attn(q, reference_points, src, spatial_shapes, level_start_index,
+                           key_padding_mask)))
+        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(ffn))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None, d_model=256, num_queries=300):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)]) \
+            if num_layers > 0 else []
+        self.num_layers = num_layers
+        self.norm = norm
+        self.d_model = d_model
+        self.num_queries = num_queries
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel centres of every level, normalised by the valid extent, then re-scaled into
+        every level's frame: [N, S, L, 2]."""
+        shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist()
+                  if isinstance(spatial_shapes, Tensor) else spatial_shapes)]
+        per_level = []
+        for lvl, (H, W) in enumerate(shapes):
+            ry, rx = torch.meshgrid(
+                torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device),
+                torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device),
+                indexing="ij")
+            ry = ry.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+            rx = rx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+            per_level.append(torch.stack((rx, ry), -1))
+        ref = torch.cat(per_level, 1)
+        return ref[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, pos, spatial_shapes, level_start_index, valid_ratios,
+                key_padding_mask, ref_token_index=None, ref_token_coord=None,
+                shapes_list=None):
+        assert ref_token_index is None
+        output = src
+        if self.num_layers > 0:
+            reference_points = self.get_reference_points(
+                shapes_list if shapes_list is not None else spatial_shapes, valid_ratios,
+                device=src.device)
+        for layer in self.layers:
+            output = layer(src=output, pos=pos, reference_points=reference_points,
+                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                           key_padding_mask=key_padding_mask)
+        if self.norm is not None:
+            output = self.norm(output)
+        return output, None, None
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4,
+                 n_heads=8, n_points=4, decoder_sa_type="sa", module_seq=("sa", "ca", "ffn")):
+        super().__init__()
+        if sorted(module_seq) != ["ca", "ffn", "sa"]:
+            raise ValueError(f"module_seq must be a permutation of sa/ca/ffn, got {module_seq}")
+        if decoder_sa_type != "sa":
+            raise NotImplementedError("only decoder_sa_type='sa' is on the hot path")
+        self.module_seq = list(module_seq)
+        self.decoder_sa_type = decoder_sa_type
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.label_embedding = None
+        self.key_aware_type = None
+        self.key_aware_proj = None
+
+    def forward_ffn(self, tgt):
+        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(tgt2))
+
+    def forward_sa(self, tgt, query_pos, attn_mask):
+        q = k = tgt if query_pos is None else tgt + query_pos
+        tgt2 = self.self_attn(q, k, tgt, attn_mask=attn_mask)[0]
+        return self.norm2(tgt + self.dropout2(tgt2))
+
+    def forward_ca(self, tgt, query_pos, reference_points, memory, spatial_shapes,
+                   level_start_index, key_padding_mask):
+        q = tgt if query_pos is None else tgt + query_pos
+        tgt2 = self.cross_attn(q.transpose(0, 1), reference_points.transpose(0, 1).contiguous(),
+                               memory.transpose(0, 1), spatial_shapes, level_start_index,
+                               key_padding_mask).transpose(0, 1)
+        return self.norm1(tgt + self.dropout1(tgt2))
+
+    def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None,
+                tgt_key_padding_mask=None, tgt_reference_points=None, memory=None,
+                memory_key_padding_mask=None, memory_level_start_index=None,
+                memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
+                cross_attn_mask=None):
+        for name in self.module_seq:
+            if name == "ffn":
+                tgt = self.forward_ffn(tgt)
+            elif name == "ca":
+                tgt = self.forward_ca(tgt, tgt_query_pos, tgt_reference_points, memory,
+                                      memory_spatial_shapes, memory_level_start_index,
+                                      memory_key_padding_mask)
+            else:
+                tgt = self.forward_sa(tgt, tgt_query_pos, self_attn_mask)
+        return tgt
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False,
+                 d_model=256, query_dim=4, num_feature_levels=1,
+                 use_detached_boxes_dec_out=False):
+        super().__init__()
+        assert return_intermediate, "support return_intermediate only"
+        assert query_dim in (2, 4)
+        self.layers = nn.ModuleList([copy.deepcopy(decoder_layer) for _ in range(num_layers)]) \
+            if num_layers > 0 else []
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+        self.query_dim = query_dim
+        self.num_feature_levels = num_feature_levels
+        self.use_detached_boxes_dec_out = use_detached_boxes_dec_out
+        self.ref_point_head = MLP(query_dim // 2 * d_model, d_model, d_model, 2)
+        self.query_pos_sine_scale = None
+        self.query_scale = None
+        self.bbox_embed = None          # set by DINO: shared box-refinement heads
+        self.class_embed = None
+        self.d_model = d_model
+        self.ref_anchor_head = None
+        self.rm_detach = None
+
+    def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None,
+                memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None,
+                memory_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
+                refpoints_unsigmoid: Optional[Tensor] = None,
+                level_start_index: Optional[Tensor] = None,
+                spatial_shapes: Optional[Tensor] = None, valid_ratios: Optional[Tensor] = None):
+        output = tgt
+        intermediate = []
+        reference_points = refpoints_unsigmoid.sigmoid()
+        ref_points = [reference_points]
+        for layer_id, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[None, :]
+            else:
+                ref_in = reference_points[:, :, None] * valid_ratios[None, :]
+            query_sine_embed = gen_sineembed_for_position(ref_in[:, :, 0, :])
+            query_pos = self.ref_point_head(query_sine_embed)
+            output = layer(tgt=output, tgt_query_pos=query_pos,
+                           tgt_query_sine_embed=query_sine_embed,
+                           tgt_key_padding_mask=tgt_key_padding_mask,
+                           tgt_reference_points=ref_in, memory=memory,
+                           memory_key_padding_mask=memory_key_padding_mask,
+                           memory_level_start_index=level_start_index,
+                           memory_spatial_shapes=spatial_shapes, memory_pos=pos,
+                           self_attn_mask=tgt_mask, cross_attn_mask=memory_mask)
+            if self.bbox_embed is not None:
+                # iterative refinement: the next layer starts from this layer's box, detached
+                new_ref = (self.bbox_embed[layer_id](output)
+                           + inverse_sigmoid(reference_points)).sigmoid()
+                reference_points = new_ref.detach()
+                ref_points.append(reference_points if self.use_detached_boxes_dec_out else new_ref)
+            intermediate.append(self.norm(output))
+        return [[x.transpose(0, 1) for x in intermediate],
+                [r.transpose(0, 1) for r in ref_points]]
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_queries=300, num_encoder_layers=6,
+                 num_unicoder_layers=0, num_decoder_layers=6, dim_feedforward=2048, dropout=0.0,
+                 activation="relu", normalize_before=False, return_intermediate_dec=False,
+                 query_dim=4, num_patterns=0, modulate_hw_attn=False, deformable_encoder=False,
+                 deformable_decoder=False, num_feature_levels=1, enc_n_points=4, dec_n_points=4,
+                 use_deformable_box_attn=False, box_attn_type="roi_align",
+                 learnable_tgt_init=False, decoder_query_perturber=None,
+                 add_channel_attention=False, add_pos_value=False, random_refpoints_xy=False,
+                 two_stage_type="no", two_stage_pat_embed=0, two_stage_add_query_num=0,
+                 two_stage_learn_wh=False, two_stage_keep_all_tokens=False, dec_layer_number=None,
+                 rm_enc_query_scale=True, rm_dec_query_scale=True, rm_self_attn_layers=None,
+                 key_aware_type=None, layer_share_type=None, rm_detach=None,
+                 decoder_sa_type="ca", module_seq=("sa", "ca", "ffn"), embed_init_tgt=False,
+                 use_detached_boxes_dec_out=False):
+        super().__init__()
+        unsupported = dict(
+            use_deformable_box_attn=use_deformable_box_attn, add_channel_attention=add_channel_attention,
+            two_stage_pat_embed=two_stage_pat_embed, two_stage_add_query_num=two_stage_add_query_num,
+            two_stage_keep_all_tokens=two_stage_keep_all_tokens, dec_layer_number=dec_layer_number,
+            rm_self_attn_layers=rm_self_attn_layers, key_aware_type=key_aware_type,
+            layer_share_type=layer_share_type, rm_detach=rm_detach,
+            decoder_query_perturber=decoder_query_perturber, num_patterns=num_patterns,
+            random_refpoints_xy=random_refpoints_xy)
+        for k, v in unsupported.items():
+            if v:
+                raise NotImplementedError(f"DeformableTransformer option {k}={v!r} is off the hot path")
+        assert deformable_encoder and deformable_decoder, "only the deformable enc/dec is built"
+        assert query_dim == 4 and learnable_tgt_init
+        assert two_stage_type in ("no", "standard"), f"unknown param {two_stage_type} of two_stage_type"
+        self.num_feature_levels = num_feature_levels
+        self.num_encoder_layers = num_encoder_layers
+        self.num_unicoder_layers = num_unicoder_layers
+        self.num_decoder_layers = num_decoder_layers
+        self.deformable_encoder, self.deformable_decoder = True, True
+        self.two_stage_keep_all_tokens = False
+        self.num_queries = num_queries
+        self.random_refpoints_xy = False
+        self.use_detached_boxes_dec_out = use_detached_boxes_dec_out
+        self.decoder_sa_type = decoder_sa_type
+        self.d_model, self.nhead, self.dec_layers = d_model, nhead, num_decoder_layers
+        self.num_patterns = 0
+
+        enc_layer = DeformableTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, enc_n_points)
+        self.encoder = TransformerEncoder(enc_layer, num_encoder_layers,
+                                          nn.LayerNorm(d_model) if normalize_before else None,
+                                          d_model=d_model, num_queries=num_queries)
+        dec_layer = DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, dec_n_points,
+                                                      decoder_sa_type=decoder_sa_type,
+                                                      module_seq=module_seq)
+        self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, nn.LayerNorm(d_model),
+                                          return_intermediate=return_intermediate_dec,
+                                          d_model=d_model, query_dim=query_dim,
+                                          num_feature_levels=num_feature_levels,
+                                          use_detached_boxes_dec_out=use_detached_boxes_dec_out)
+        self.level_embed = None
+        if num_feature_levels > 1 and num_encoder_layers > 0:
+            self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.learnable_tgt_init = True
+        self.embed_init_tgt = embed_init_tgt
+        if (two_stage_type != "no" and embed_init_tgt) or two_stage_type == "no":
+            self.tgt_embed = nn.Embedding(num_queries, d_model)
+            nn.init.normal_(self.tgt_embed.weight.data)
+        else:
+            self.tgt_embed = None
+        self.two_stage_type = two_stage_type
+        self.two_stage_pat_embed = 0
+        self.two_stage_add_query_num = 0
+        self.two_stage_learn_wh = two_stage_learn_wh
+        if two_stage_type == "standard":
+            self.enc_output = nn.Linear(d_model, d_model)
+            self.enc_output_norm = nn.LayerNorm(d_model)
+            self.two_stage_wh_embedding = nn.Embedding(1, 2) if two_stage_learn_wh else None
+        if two_stage_type == "no":
+            self.refpoint_embed = nn.Embedding(num_queries, 4)
+        self.enc_out_class_embed = None   # set by DINO
+        self.enc_out_bbox_embed = None
+        self.dec_layer_number = None
+        self._reset_parameters()
+        self.rm_self_attn_layers = None
+        self.rm_detach = None
+        self._meta_cache = {}
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        if self.num_feature_levels > 1 and self.level_embed is not None:
+            nn.init.normal_(self.level_embed)
+        if self.two_stage_learn_wh:
+            nn.init.constant_(self.two_stage_wh_embedding.weight, math.log(0.05 / (1 - 0.05)))
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        valid_H = torch.sum(~mask[:, :, 0], 1)
+        valid_W = torch.sum(~mask[:, 0, :], 1)
+        return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
+
+    def _level_meta(self, shapes_list, device):
+        """int64 device tensors [L,2] / [L] for the MSDA op, cached per geometry so the step
+        issues no per-call host->device copies."""
+        key = (tuple(shapes_list), str(device))
+        hit = self._meta_cache.get(key)
+        if hit is None:
+            spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=device)
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)),
+                                           spatial_shapes.prod(1).cumsum(0)[:-1]))
+            if len(self._meta_cache) > 64:
+                self._meta_cache.clear()
+            hit = self._meta_cache[key] = (spatial_shapes, level_start_index)
+        return hit
+
+    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None):
+        src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes_list = [], [], [], []
+        for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
+            bs, c, h, w = src.shape
+            shapes_list.append((h, w))
+            src_flatten.append(src.flatten(2).transpose(1, 2))
+            mask_flatten.append(mask.flatten(1))
+            pos_embed = pos_embed.flatten(2).transpose(1, 2)
+            if self.num_feature_levels > 1 and self.level_embed is not None:
+                pos_embed = pos_embed + self.level_embed[lvl].view(1, 1, -1)
+            lvl_pos_embed_flatten.append(pos_embed)
+        src_flatten = torch.cat(src_flatten, 1)
+        mask_flatten = torch.cat(mask_flatten, 1)
+        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+        spatial_shapes, level_start_index = self._level_meta(shapes_list, src_flatten.device)
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+
+        memory, _, _ = self.encoder(src_flatten, pos=lvl_pos_embed_flatten,
+                                    level_start_index=level_start_index,
+                                    spatial_shapes=spatial_shapes, valid_ratios=valid_ratios,
+                                    key_padding_mask=mask_flatten, shapes_list=shapes_list)
+
+        if self.two_stage_type == "standard":
+            input_hw = self.two_stage_wh_embedding.weight[0] if self.two_stage_learn_wh else None
+            output_memory, output_proposals = gen_encoder_output_proposals(
+                memory, mask_flatten, shapes_list, input_hw)
+            output_memory = self.enc_output_norm(self.enc_output(output_memory))
+            enc_class = self.enc_out_class_embed(output_memory)
+            enc_coord = self.enc_out_bbox_embed(output_memory) + output_proposals   # logits
+            topk_idx = torch.topk(enc_class.max(-1)[0], self.num_queries, dim=1)[1]
+            refpoint_embed_undetach = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
+            refpoint_embed_ = refpoint_embed_undetach.detach()
+            init_box_proposal = torch.gather(
+                output_proposals, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4)).sigmoid()
+            tgt_undetach = torch.gather(output_memory, 1,
+                                        topk_idx.unsqueeze(-1).repeat(1, 1, self.d_model))
+            if self.embed_init_tgt:
+                tgt_ = self.tgt_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
+            else:
+                tgt_ = tgt_undetach.detach()
+            if refpoint_embed is not None:
+                refpoint_embed = torch.cat([refpoint_embed, refpoint_embed_], dim=1)
+                tgt = torch.cat([tgt, tgt_], dim=1)
+            else:
+                refpoint_embed, tgt = refpoint_embed_, tgt_
+        else:
+            tgt_ = self.tgt_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
+            refpoint_embed_ = self.refpoint_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
+            if refpoint_embed is not None:
+                refpoint_embed = torch.cat([refpoint_embed, refpoint_embed_], dim=1)
+                tgt = torch.cat([tgt, tgt_], dim=1)
+            else:
+                refpoint_embed, tgt = refpoint_embed_, tgt_
+            init_box_proposal = refpoint_embed_.sigmoid()
+
+        hs, references = self.decoder(
+            tgt=tgt.transpose(0, 1), memory=memory.transpose(0, 1),
+            memory_key_padding_mask=mask_flatten, pos=lvl_pos_embed_flatten.transpose(0, 1),
+            refpoints_unsigmoid=refpoint_embed.transpose(0, 1),
+            level_start_index=level_start_index, spatial_shapes=spatial_shapes,
+            valid_ratios=valid_ratios, tgt_mask=attn_mask)
+
+        if self.two_stage_type == "standard":
+            hs_enc = tgt_undetach.unsqueeze(0)
+            ref_enc = refpoint_embed_undetach.sigmoid().unsqueeze(0)
+        else:
+            hs_enc = ref_enc = None
+        return hs, references, hs_enc, ref_enc, init_box_proposal
+
+
+def build_deformable_transformer(args):
+    if getattr(args, "decoder_layer_noise", False):
+        raise NotImplementedError("decoder_layer_noise is off in every DA config")
+    return DeformableTransformer(
+        d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads,
+        num_queries=args.num_queries, dim_feedforward=args.dim_feedforward,
+        num_encoder_layers=args.enc_layers, num_unicoder_layers=args.unic_layers,
+        num_decoder_layers=args.dec_layers, normalize_before=args.pre_norm,
+        return_intermediate_dec=True, query_dim=args.query_dim,
+        activation=args.transformer_activation, num_patterns=args.num_patterns,
+        modulate_hw_attn=True, deformable_encoder=True, deformable_decoder=True,
+        num_feature_levels=args.num_feature_levels, enc_n_points=args.enc_n_points,
+        dec_n_points=args.dec_n_points, use_deformable_box_attn=args.use_deformable_box_attn,
+        box_attn_type=getattr(args, "box_attn_type", "roi_align"), learnable_tgt_init=True,
+        decoder_query_perturber=None, add_channel_attention=args.add_channel_attention,
+        add_pos_value=getattr(args, "add_pos_value", False),
+        random_refpoints_xy=args.random_refpoints_xy, two_stage_type=args.two_stage_type,
+        two_stage_pat_embed=args.two_stage_pat_embed,
+        two_stage_add_query_num=args.two_stage_add_query_num,
+        two_stage_learn_wh=args.two_stage_learn_wh,
+        two_stage_keep_all_tokens=args.two_stage_keep_all_tokens,
+        dec_layer_number=args.dec_layer_number, rm_self_attn_layers=None, key_aware_type=None,
+        layer_share_type=None, rm_detach=None, decoder_sa_type=args.decoder_sa_type,
+        module_seq=args.decoder_module_seq, embed_init_tgt=args.embed_init_tgt,
+        use_detached_boxes_dec_out=getattr(args, "use_detached_boxes_dec_out", False))

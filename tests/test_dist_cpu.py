@@ -1,0 +1,107 @@
+"""CPU, world_size 2 over gloo: the flat-bucket gradient all-reduce (datr_amd/dist.py) and the
+criterion's num_boxes all-reduce, run as real processes (torch.multiprocessing.spawn)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.shared = nn.Linear(16, 16)
+        self.heads = nn.ModuleList([self.shared for _ in range(3)])     # aliased, like DINO's heads
+        self.unused = nn.Linear(16, 4)                                  # never in the graph
+        self.sometimes = nn.Linear(16, 4)                               # only on rank 0
+
+    def forward(self, x, use_sometimes):
+        h = torch.relu(self.a(x))
+        for m in self.heads:
+            h = m(h)
+        out = h.sum()
+        if use_sometimes:
+            out = out + self.sometimes(h).sum()
+        return out
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from datr_amd.dist import GradAllReducer, init_distributed
+    init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = Toy()
+    ref = Toy()
+    ref.load_state_dict(model.state_dict())
+    # tiny buckets so that several are exercised
+    red = GradAllReducer(model, bucket_mb=0.0005, first_bucket_mb=0.0002)
+    assert len(red.buckets) >= 3
+    assert sum(len(b.params) for b in red.buckets) == len(list(model.parameters()))
+    for step in range(3):
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 * step + rank))
+        red.zero_grad()
+        model(x, use_sometimes=(rank == 0)).backward()
+        red.finish()
+        # expected: average over ranks of the local gradients (missing grads count as zeros)
+        ref.zero_grad()
+        ref(x, use_sometimes=(rank == 0)).backward()
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            local = torch.zeros_like(q) if q.grad is None else q.grad.clone()
+            dist.all_reduce(local)
+            torch.testing.assert_close(p.grad, local / world, rtol=1e-6, atol=1e-7, msg=n)
+        # grads are still views of the flat buffers (no copy-out happened)
+        for b in red.buckets:
+            for p in b.params:
+                assert p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
+    # criterion: num_boxes is the world average of the per-rank counts, clamped at 1
+    from datr_amd.criterion import SetCriterion
+
+    class M(nn.Module):
+        def forward(self, outputs, targets):
+            return [(torch.arange(len(t["labels"])), torch.arange(len(t["labels"]))) for t in targets]
+    crit = SetCriterion(3, M(), {}, 0.25, ["labels", "boxes", "cardinality"])
+    n_gt = 1 if rank == 0 else 3
+    out = {"pred_logits": torch.zeros(1, 5, 3), "pred_boxes": torch.full((1, 5, 4), 0.5),
+           "dn_meta": None}
+    tg = [{"labels": torch.ones(n_gt, dtype=torch.long), "boxes": torch.full((n_gt, 4), 0.25)}]
+    crit.eval()
+    losses = crit(out, tg)
+    # L1 = |0.5-0.25| * 4 * n_gt / num_boxes with num_boxes = (1+3)/2 = 2
+    torch.testing.assert_close(losses["loss_bbox"], torch.tensor(1.0 * n_gt / 2.0))
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_flat_bucket_allreduce_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_reducer_single_process_views_and_unused():
+    from datr_amd.dist import GradAllReducer
+    torch.manual_seed(0)
+    model = Toy()
+    red = GradAllReducer(model, bucket_mb=0.0005, first_bucket_mb=0.0002)
+    red.zero_grad()
+    model(torch.randn(3, 8), use_sometimes=False).backward()
+    red.finish()
+    assert torch.count_nonzero(model.unused.weight.grad) == 0
+    assert torch.count_nonzero(model.sometimes.weight.grad) == 0
+    assert torch.count_nonzero(model.shared.weight.grad) > 0
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+    before = model.a.weight.detach().clone()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+    opt.step()
+    assert not torch.equal(before, model.a.weight)

@@ -1,0 +1,148 @@
+"""CPU: the host-side mirror of the reference model (datr_amd.detector / transformer /
+criterion / ...) against golden vectors captured from the reference
+(tests/golden/make_golden_model.py).  MSDA runs through the C oracle here (test-only
+monkeypatch, tests/helpers.py); the same comparisons run on the HIP path in
+tests/test_model_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (build_model, check_gradients, check_training_step, load_npz,
+                     patch_msda_with_oracle, run_training_step, t)
+
+
+@pytest.fixture(scope="module")
+def units():
+    return load_npz("model_units.npz")
+
+
+def test_state_dict_manifest_matches_reference():
+    g = load_npz("model_step.npz")
+    _, model, _, _ = build_model()
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["state_shapes"]]
+    assert "global_proto" not in sd and "Amount" not in sd
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 47_773_340
+    # the six decoder heads alias one module, also reachable through transformer.decoder
+    assert model.class_embed[0] is model.class_embed[5] is model.transformer.decoder.class_embed[3]
+    assert model.transformer.enc_out_class_embed is not model.class_embed[0]
+
+
+def test_weight_dict_matches_reference():
+    g = load_npz("model_step.npz")
+    _, _, criterion, _ = build_model()
+    assert list(criterion.weight_dict.keys()) == [str(k) for k in g["weight_keys"]]
+    np.testing.assert_allclose(list(criterion.weight_dict.values()), g["weight_values"])
+
+
+def test_position_embedding(units):
+    from datr_amd.backbone import PositionEmbeddingSineHW
+    from datr_amd.nested import NestedTensor
+    pe = PositionEmbeddingSineHW(128, temperatureH=20, temperatureW=20, normalize=True)
+    out = pe(NestedTensor(torch.zeros(2, 4, 13, 17), t(units["pe_mask"])))
+    torch.testing.assert_close(out, t(units["pe_out"]), rtol=1e-5, atol=1e-6)
+
+
+def test_sine_query_embedding(units):
+    from datr_amd.transformer import gen_sineembed_for_position
+    pos = t(units["sine_in"])
+    torch.testing.assert_close(gen_sineembed_for_position(pos), t(units["sine_out4"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gen_sineembed_for_position(pos[..., :2]), t(units["sine_out2"]), rtol=1e-5, atol=1e-6)
+
+
+def test_encoder_output_proposals(units):
+    from datr_amd.transformer import gen_encoder_output_proposals
+    om, op = gen_encoder_output_proposals(t(units["prop_memory"]), t(units["prop_mask"]),
+                                          t(units["prop_shapes"]))
+    assert torch.equal(om, t(units["prop_out_memory"]))
+    ref = t(units["prop_out"])
+    assert torch.equal(torch.isinf(op), torch.isinf(ref))
+    fin = ~torch.isinf(ref)
+    torch.testing.assert_close(op[fin], ref[fin], rtol=1e-6, atol=1e-6)
+    om2, op2 = gen_encoder_output_proposals(t(units["prop_memory"]), t(units["prop_mask"]),
+                                            [(6, 8), (3, 4)])           # python-list form
+    assert torch.equal(op2, op)
+
+
+def test_inverse_sigmoid_and_focal_and_giou(units):
+    from datr_amd.boxes import box_cxcywh_to_xyxy, generalized_box_iou
+    from datr_amd.criterion import sigmoid_focal_loss
+    from datr_amd.nested import inverse_sigmoid
+    assert torch.equal(inverse_sigmoid(t(units["invsig_in"])), t(units["invsig_out"]))
+    out = sigmoid_focal_loss(t(units["focal_logits"]), t(units["focal_targets"]), 7.0, alpha=0.25, gamma=2)
+    torch.testing.assert_close(out, t(units["focal_out"]), rtol=1e-6, atol=1e-7)
+    giou = generalized_box_iou(box_cxcywh_to_xyxy(t(units["boxes1"])), box_cxcywh_to_xyxy(t(units["boxes2"])))
+    assert torch.equal(giou, t(units["giou"]))
+
+
+def test_hungarian_indices_bit_exact(units):
+    from datr_amd.matcher import HungarianMatcher
+    m = HungarianMatcher(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0)
+    targets = [{"labels": t(units[f"match_tlabels{i}"]), "boxes": t(units[f"match_tboxes{i}"])} for i in range(2)]
+    idx = m({"pred_logits": t(units["match_logits"]), "pred_boxes": t(units["match_boxes"])}, targets)
+    for i in range(2):
+        assert torch.equal(idx[i][0], t(units[f"match_src{i}"]))
+        assert torch.equal(idx[i][1], t(units[f"match_tgt{i}"]))
+
+
+def test_prototypes_running_update(units):
+    from datr_amd.domain import get_prototype_class_wise
+    gp, ga = torch.zeros(9, 256), torch.zeros(9)
+    p1 = get_prototype_class_wise(t(units["proto_q"]), t(units["proto_logits"]), 9, global_proto=gp, global_amount=ga)
+    p2 = get_prototype_class_wise(t(units["proto_q2"]), t(units["proto_logits2"]), 9, global_proto=p1[2], global_amount=p1[3])
+    for n, p in (("1", p1), ("2", p2)):
+        torch.testing.assert_close(p[0], t(units["proto_out" + n]), rtol=1e-5, atol=1e-6)
+        assert torch.equal(p[1], t(units["proto_map" + n]))           # argmax class map: exact
+        torch.testing.assert_close(p[2], t(units["proto_global" + n]), rtol=1e-5, atol=1e-6)
+        assert torch.equal(p[3], t(units["proto_amount" + n]))
+        assert not p[2].requires_grad
+
+
+def test_full_training_step_matches_reference(monkeypatch):
+    patch_msda_with_oracle(monkeypatch, kind="grid_sample")
+    g = load_npz("model_step.npz")
+    _, model, criterion, _ = build_model()
+    out, loss_dict, indices_list, total = run_training_step(model, criterion, "cpu", g)
+    assert len(loss_dict) == 82
+    # same arithmetic as the reference's CPU path -> far tighter than the 1e-3 contract
+    check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-5, loss_rtol=1e-5)
+    check_gradients(model, g, rtol=1e-4)
+
+
+def test_eval_forward_and_postprocess(monkeypatch):
+    patch_msda_with_oracle(monkeypatch, kind="grid_sample")
+    import synth
+    from datr_amd.detector import PostProcess
+    g = load_npz("model_eval.npz")
+    _, model, _, _ = build_model()
+    model.eval()
+    imgs, _ = synth.synth_batch()
+    with torch.no_grad():
+        out = model(imgs)
+        assert "da_output" not in out and out["dn_meta"] is None
+        res = PostProcess(num_select=100)(out, t(g["sizes"]))
+    torch.testing.assert_close(out["pred_logits"], t(g["pred_logits"]), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out["pred_boxes"], t(g["pred_boxes"]), rtol=1e-3, atol=1e-3)
+    # top-k selection is discontinuous: compare as a function -- same inputs, same indices
+    ref_out = {"pred_logits": t(g["pred_logits"]), "pred_boxes": t(g["pred_boxes"])}
+    res_ref = PostProcess(num_select=100)(ref_out, t(g["sizes"]))
+    assert torch.equal(torch.stack([r["labels"] for r in res_ref]), t(g["labels"]))
+    torch.testing.assert_close(torch.stack([r["scores"] for r in res_ref]), t(g["scores"]))
+    torch.testing.assert_close(torch.stack([r["boxes"] for r in res_ref]), t(g["boxes"]))
+    assert len(res) == 2 and res[0]["boxes"].shape == (100, 4)
+
+
+def test_source_only_switch(monkeypatch):
+    """Non-reference flag for BASELINE configs 1-2: no DA branch, B source images only."""
+    patch_msda_with_oracle(monkeypatch)
+    import synth
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    _, model, criterion, _ = build_model()
+    model.domain_adaptation = False
+    model.train()
+    imgs, targets = synth.synth_batch()
+    out = model(nested_tensor_from_tensor_list(imgs[:1]), targets)
+    assert "da_output" not in out
+    losses = criterion(out, targets)
+    assert "loss_backbone_DA" not in losses and "loss_ce_dn_4" in losses
