@@ -391,6 +391,13 @@ class DeformableTransformer(nn.Module):
         if self.two_stage_learn_wh:
             nn.init.constant_(self.two_stage_wh_embedding.weight, math.log(0.05 / (1 - 0.05)))
 
+    def select_queries(self, scores: Tensor) -> Tensor:
+        """Indices [N, num_queries] of the highest-scoring encoder tokens
+        (deformable_transformer.py:342).  A method of its own because it is THE discontinuity
+        of the forward pass: parity tests pin it as a function and may substitute the
+        reference's selection when comparing what comes after it."""
+        return torch.topk(scores, self.num_queries, dim=1)[1]
+
     @staticmethod
     def get_valid_ratio(mask):
         _, H, W = mask.shape
@@ -441,7 +448,7 @@ class DeformableTransformer(nn.Module):
             output_memory = self.enc_output_norm(self.enc_output(output_memory))
             enc_class = self.enc_out_class_embed(output_memory)
             enc_coord = self.enc_out_bbox_embed(output_memory) + output_proposals   # logits
-            topk_idx = torch.topk(enc_class.max(-1)[0], self.num_queries, dim=1)[1]
+            topk_idx = self.select_queries(enc_class.max(-1)[0])
             refpoint_embed_undetach = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
             refpoint_embed_ = refpoint_embed_undetach.detach()
             init_box_proposal = torch.gather(

@@ -87,9 +87,22 @@ def main():
     criterion.train()
     samples = ref_nest(imgs)
     torch.manual_seed(123)
-    with DrawRecorder() as rec:
-        out = model(samples, targets)
+    topk_calls = []
+    real_topk = torch.topk
+
+    def rec_topk(inp, k, *a, **kw):
+        res = real_topk(inp, k, *a, **kw)
+        if k == 900:
+            topk_calls.append(res[1].clone())
+        return res
+    torch.topk = rec_topk
+    try:
+        with DrawRecorder() as rec:
+            out = model(samples, targets)
+    finally:
+        torch.topk = real_topk
     assert len(rec.draws) == 4, len(rec.draws)
+    assert len(topk_calls) == 2, len(topk_calls)      # source pass, target pass
     loss_dict, indices_list = criterion(out, targets, return_indices=True)
     wd = criterion.weight_dict
     total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
@@ -100,6 +113,7 @@ def main():
         "noise_label_p": to_np(rec.draws[0]), "noise_new_label": to_np(rec.draws[1]),
         # the reference draws {0,1} and maps to {-1,+1} afterwards (dn_components.py:84)
         "noise_rand_sign": to_np(rec.draws[2] * 2.0 - 1.0), "noise_rand_part": to_np(rec.draws[3]),
+        "topk_source": to_np(topk_calls[0]), "topk_target": to_np(topk_calls[1]),
         "pred_logits": to_np(out["pred_logits"]), "pred_boxes": to_np(out["pred_boxes"]),
         "aux_logits": to_np(torch.stack([a["pred_logits"] for a in out["aux_outputs"]])),
         "aux_boxes": to_np(torch.stack([a["pred_boxes"] for a in out["aux_outputs"]])),

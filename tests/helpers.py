@@ -77,6 +77,19 @@ def canonical_grad_norms(model):
     return out
 
 
+def force_reference_selection(model, golden, device):
+    """Test-side substitution of DeformableTransformer.select_queries: return the reference's
+    top-900 token indices (source pass first, then target pass) instead of re-deriving them."""
+    calls = [t(golden["topk_source"]).to(device), t(golden["topk_target"]).to(device)]
+    state = {"i": 0}
+
+    def forced(scores):
+        idx = calls[state["i"] % 2]
+        state["i"] += 1
+        return idx
+    model.transformer.select_queries = forced
+
+
 def run_training_step(model, criterion, device, golden):
     """One training forward + criterion + backward with the golden's CDN noise injected."""
     import synth
