@@ -12,7 +12,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdatr_hip.so")
+# DATR_HIP_LIB points at an alternative build of the same ABI (e.g. the -DDATR_PROBE build used
+# for kernel ablations); there is still no non-native fallback.
+LIB_PATH = os.environ.get("DATR_HIP_LIB") or os.path.join(_HERE, "lib", "libdatr_hip.so")
 ABI_VERSION = 1
 
 _i64 = ctypes.c_int64
@@ -24,6 +26,7 @@ _SIGNATURES = {
     "datr_msda_forward_f64": [_vp] * 5 + [_i64] * 7 + [_vp, _vp],
     "datr_msda_backward_f32": [_vp] * 6 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
     "datr_msda_backward_f64": [_vp] * 6 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
+    "datr_msda_backward_tiled_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
     "datr_msda_uses_fast_path": [_i64] * 5,
 }
 

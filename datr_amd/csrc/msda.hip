@@ -30,6 +30,7 @@
 #include <cstdint>
 
 #include "datr_hip.h"
+#include "msda_tiled.h"
 
 namespace {
 
@@ -582,6 +583,52 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
         case 16: return launch_bwd_rows<4>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn, st);
         default: return backward_generic<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, st);
     }
+}
+
+int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                                 const int64_t *level_start, const int64_t *shapes_host,
+                                 const int64_t *level_start_host, const float *loc,
+                                 const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                 int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                 float *grad_loc, float *grad_attn, void *stream) {
+    // The tiled kernel needs the level geometry on the host (grid size) and the
+    // pixels-are-the-queries layout; anything else takes the row kernel.
+    bool tiled = shapes_host && level_start_host && D == 32 && Lq == S && L >= 1 &&
+                 L <= DATR_TILED_MAX_LEVELS && P >= 1 && P <= 4 && N > 0 &&
+                 S * M * D * 4 < (int64_t)kOutOfRange;
+    DatrTiledMeta meta;
+    if (tiled) {
+        meta.L = (int)L;
+        int64_t expect = 0;
+        int base = 0;
+        for (int l = 0; l < L; ++l) {
+            const int64_t H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+            if (H <= 0 || W <= 0 || H > 32000 || W > 32000 || level_start_host[l] != expect) {
+                tiled = false;
+                break;
+            }
+            meta.lv[l].H = (int)H;
+            meta.lv[l].W = (int)W;
+            meta.lv[l].start = (int)expect;
+            meta.lv[l].tiles_x = (int)((W + DATR_TILE_W - 1) / DATR_TILE_W);
+            meta.lv[l].tiles_y = (int)((H + DATR_TILE_H - 1) / DATR_TILE_H);
+            meta.lv[l].tile_base = base;
+            base += meta.lv[l].tiles_x * meta.lv[l].tiles_y;
+            expect += H * W;
+        }
+        meta.total_tiles = base;
+        if (expect != S) tiled = false;
+    }
+    if (!tiled)
+        return datr_msda_backward_f32(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L,
+                                      Lq, P, grad_value, grad_loc, grad_attn, stream);
+    if (!grad_out || !value || !loc || !attn || !grad_value || !grad_loc || !grad_attn)
+        return DATR_EINVAL;
+    if (hipMemsetAsync(grad_value, 0, (size_t)(N * S * M * D) * sizeof(float),
+                       (hipStream_t)stream) != hipSuccess)
+        return DATR_ELAUNCH;
+    return datr_internal_msda_bwd_tiled_d32(grad_out, value, loc, attn, &meta, N, S, M, P,
+                                            grad_value, grad_loc, grad_attn, stream);
 }
 
 int datr_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

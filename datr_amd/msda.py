@@ -58,6 +58,22 @@ def _as_int64(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == torch.int64 else t.to(torch.int64)
 
 
+_HOST_META = {}
+
+
+def _host_meta(shapes: torch.Tensor, lsi: torch.Tensor):
+    """Host copies (numpy int64) of the two small geometry tensors, cached by storage address
+    and version so that a training loop pays the device->host copy once per geometry, not per
+    call (datr_amd.transformer caches the device tensors per feature-map geometry)."""
+    key = (shapes.data_ptr(), shapes._version, lsi.data_ptr(), lsi._version, shapes.shape[0])
+    hit = _HOST_META.get(key)
+    if hit is None:
+        if len(_HOST_META) > 256:
+            _HOST_META.clear()
+        hit = _HOST_META[key] = (shapes.cpu().numpy().copy(), lsi.cpu().numpy().copy())
+    return hit
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                            im2col_step: int):
     """-> Tensor [N, Lq, M*D]  (same contract as MSDA.ms_deform_attn_forward)."""
@@ -96,11 +112,20 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
-        fn = getattr(_native.lib, f"datr_msda_backward_{sfx}")
-        rc = fn(grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
-                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
-                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                _native.current_stream_ptr(value.device))
+        stream = _native.current_stream_ptr(value.device)
+        if sfx == "f32" and Lq == S and D == 32:
+            # encoder self-attention: the query-tiled kernel needs the geometry on the host
+            sh_host, ls_host = _host_meta(shapes, lsi)
+            rc = _native.lib.datr_msda_backward_tiled_f32(
+                grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+                sh_host.ctypes.data, ls_host.ctypes.data, sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                grad_loc.data_ptr(), grad_attn.data_ptr(), stream)
+        else:
+            fn = getattr(_native.lib, f"datr_msda_backward_{sfx}")
+            rc = fn(grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+                    sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                    grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), stream)
     _native.check(rc, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_attn]
 

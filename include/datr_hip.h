@@ -70,6 +70,21 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
                            int64_t L, int64_t Lq, int64_t P,
                            float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
+/* Same contract as datr_msda_backward_f32, for callers that also hold HOST copies of `shapes`
+ * and `level_start` (the reference builds both from python ints,
+ * /root/reference/models/dino/deformable_transformer.py:267-290, so a binding has them for
+ * free).  When Lq == S -- the queries are the pyramid's own pixels, i.e. the encoder's
+ * self-attention -- and D == 32, a query-tiled kernel accumulates grad_value in LDS (fixed
+ * point) and flushes each touched row once, instead of one global float atomic per
+ * contribution; every other shape falls through to datr_msda_backward_f32.  The host arrays
+ * are only read during the call. */
+int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                                 const int64_t *level_start, const int64_t *shapes_host,
+                                 const int64_t *level_start_host, const float *loc,
+                                 const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                 int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                 float *grad_loc, float *grad_attn, void *stream);
+
 /* Double-precision twins (generic kernels; they exist so the reference's gradcheck-in-double
  * op test, /root/reference/models/dino/ops/test.py:63-86, can be restated). */
 int datr_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

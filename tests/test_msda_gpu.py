@@ -121,6 +121,50 @@ def test_matches_c_oracle(M, O, dev, case):
     torch.testing.assert_close(gl[keep], rl[keep], **tol(dtype, 100))
 
 
+def pyramid_locs(shapes, N, Mh, P, spread, seed):
+    """Encoder-style sampling locations: every pyramid pixel is a query whose reference point
+    is its own centre; offsets ~ N(0, spread px) in the target level's pixels."""
+    g = torch.Generator().manual_seed(seed)
+    refs = []
+    for h, w in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)
+    S, L = ref.shape[0], len(shapes)
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+    off = torch.randn(N, S, Mh, L, P, 2, generator=g) * spread
+    return (ref.view(1, S, 1, 1, 1, 2) + off / wh).contiguous()
+
+
+@pytest.mark.parametrize("shapes,spread", [
+    ([(20, 27), (10, 14), (5, 7), (3, 4)], 1.5),      # ragged tiles on every level
+    ([(20, 27), (10, 14), (5, 7), (3, 4)], 12.0),     # offsets far beyond any window -> fallback
+    ([(33, 50), (17, 25)], 3.0),                      # L = 2, several tiles per level
+    ([(8, 16)], 0.5),                                 # exactly one full tile
+])
+def test_tiled_backward_for_pyramid_queries(M, O, dev, shapes, spread):
+    """Lq == S takes the query-tiled backward (LDS fixed-point accumulation + flush)."""
+    N, Mh, D, P = 2, 8, 32, 4
+    value, sh, lsi, _, attn = O.random_inputs(N, 1, Mh, D, shapes, P, seed=11)
+    S = value.shape[1]
+    loc = pyramid_locs(shapes, N, Mh, P, spread, seed=5)
+    g = torch.Generator().manual_seed(6)
+    attn = torch.softmax(torch.randn(N, S, Mh, len(shapes) * P, generator=g), -1).view(N, S, Mh, len(shapes), P)
+    go = torch.randn(N, S, Mh * D, generator=g) * 3.0
+    out, gv, gl, ga = run_hip(M, dev, value, sh, lsi, loc, attn, go)
+    torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
+    rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
+    scale = float(rv.abs().max())
+    # fixed-point step is ~3e-8 of max|grad_out| * sum|attn| per tile; hold to 2e-6 of the max
+    torch.testing.assert_close(gv, rv, rtol=1e-4, atol=2e-6 * scale)
+    torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
+    keep = off_grid(loc, sh, eps=1e-4)
+    torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
+    # zero grad_out -> exact zeros (scale = 0 path)
+    _, gv0, gl0, ga0 = run_hip(M, dev, value, sh, lsi, loc, attn, torch.zeros_like(go))
+    assert torch.count_nonzero(gv0) == 0 and torch.count_nonzero(gl0) == 0 and torch.count_nonzero(ga0) == 0
+
+
 def test_empty_and_fully_out_of_range(M, O, dev):
     value, sh, lsi, loc, attn = O.random_inputs(1, 0, 8, 32, [(4, 4)], 4, seed=1)
     assert run_hip(M, dev, value, sh, lsi, loc, attn).shape == (1, 0, 256)

@@ -88,6 +88,19 @@ def main():
             b = lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
             fm, fmin = time_fn(f, args.iters)
             bm, bmin = time_fn(b, args.iters)
+            if os.environ.get("DATR_HIP_LIB", "").endswith("probe.so"):
+                import ctypes
+                from datr_amd import _native
+                buf = (ctypes.c_ulonglong * 8)()
+                _native.lib.datr_probe_phase_cycles(buf, 1)
+                b()
+                torch.cuda.synchronize()
+                _native.lib.datr_probe_phase_cycles(buf, 1)
+                tot = sum(buf) or 1
+                print("phase cycles (thread 0 of every block, one bwd call): " + ", ".join(
+                    f"{n}={100 * v / tot:.1f}%" for n, v in zip(
+                        ["maxgo", "A:geom", "win-zero", "B:gather+add", "B-barrier", "C:flush"], buf)),
+                    f"total={tot / 1e6:.1f} Mcycles")
             print(json.dumps({
                 "dist": dist, "Lq": Lq,
                 "fwd_us_median": round(fm, 2), "fwd_us_min": round(fmin, 2),
