@@ -41,6 +41,18 @@ def main():
     end_idx = marks[(n_steps - 1) * a.per_step]
     window = rows[start_idx:end_idx]          # exactly `steps` periods of the step cycle
     t0, t1 = int(window[0][ks]), int(window[-1][ks])
+    # GPU busy time = union of kernel intervals in the window
+    busy, cur_s, cur_e = 0, None, None
+    for r in window:
+        a_, b_ = int(r[ks]), int(r[ke])
+        if cur_e is None or a_ > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = a_, b_
+        else:
+            cur_e = max(cur_e, b_)
+    if cur_e is not None:
+        busy += cur_e - cur_s
     agg = defaultdict(lambda: [0, 0])
     for r in window:
         d = int(r[ke]) - int(r[ks])
@@ -53,12 +65,14 @@ def main():
     for name, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         out.append((name, f"{c / a.steps:.1f}", f"{d / a.steps / 1e6:.3f}", f"{d / c / 1e3:.1f}",
                     f"{100 * d / total:.2f}"))
+    print(f"# gpu_busy_ms_per_step={busy / a.steps / 1e6:.1f} (idle {wall - busy / a.steps / 1e6:.1f})")
     print(f"# steps={a.steps} wall_ms_per_step={wall:.1f} kernel_ms_per_step={total / a.steps / 1e6:.1f} "
           f"launches_per_step={len(window) / a.steps:.0f} distinct={len(agg)}")
     for row in out[:a.top + 1]:
         print(", ".join(row))
     if a.out:
         with open(a.out, "w") as f:
+            f.write(f"# gpu_busy_ms_per_step={busy / a.steps / 1e6:.1f}\n")
             f.write(f"# steady-state steps={a.steps} wall_ms_per_step={wall:.1f} "
                     f"kernel_ms_per_step={total / a.steps / 1e6:.1f} "
                     f"launches_per_step={len(window) / a.steps:.0f}\n")
