@@ -132,7 +132,7 @@ class MsdaTimer:
 
 
 def cpu_baseline():
-    """Reference-equivalent CPU step (torch CPU kernels + the C oracle for MSDA) on the host
+    """Reference-equivalent CPU step (torch CPU kernels + the oracle for MSDA / focal loss) on the host
     cores: ONE training step at 640x640, B=1 (2 images), after one un-timed build."""
     from datr_amd import msda
     from datr_amd.config import c2f_args, get_param_dict
@@ -145,8 +145,11 @@ def cpu_baseline():
     def bwd(value, shapes, lsi, loc, attn, go, step):
         return list(O.msda_backward(value, shapes, lsi, loc, attn, go))
 
-    saved = (msda.ms_deform_attn_forward, msda.ms_deform_attn_backward)
+    from datr_amd import criterion as crit_mod
+    from oracle import focal_oracle
+    saved = (msda.ms_deform_attn_forward, msda.ms_deform_attn_backward, crit_mod.focal_loss_sums)
     msda.ms_deform_attn_forward, msda.ms_deform_attn_backward = fwd, bwd
+    crit_mod.focal_loss_sums = focal_oracle.focal_sums_torch
     try:
         cfg = c2f_args(device="cpu")
         torch.manual_seed(0)
@@ -166,7 +169,7 @@ def cpu_baseline():
         opt.step()
         dt = time.perf_counter() - t0
     finally:
-        msda.ms_deform_attn_forward, msda.ms_deform_attn_backward = saved
+        msda.ms_deform_attn_forward, msda.ms_deform_attn_backward, crit_mod.focal_loss_sums = saved
     return {"value": round(2.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"1 training step, 1 source + 1 target image 640x640 (BASELINE config 1 "

@@ -28,6 +28,10 @@ _SIGNATURES = {
     "datr_msda_backward_f64": [_vp] * 6 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
     "datr_msda_backward_tiled_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
     "datr_msda_uses_fast_path": [_i64] * 5,
+    "datr_focal_loss_forward_f32": [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
+                                    _vp, _vp, _vp],
+    "datr_focal_loss_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float,
+                                     ctypes.c_float, _vp, _vp],
 }
 
 
@@ -47,6 +51,8 @@ def _load() -> ctypes.CDLL:
             f"libdatr_hip.so ABI {lib.datr_abi_version()} != expected {ABI_VERSION}")
     lib.datr_strerror.restype = ctypes.c_char_p
     lib.datr_strerror.argtypes = [ctypes.c_int]
+    lib.datr_focal_scratch_floats.restype = ctypes.c_int64
+    lib.datr_focal_scratch_floats.argtypes = [_i64, _i64]
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes

@@ -10,6 +10,14 @@ order of creation and every normaliser follow the reference (Appe
   * loss_da: mean BCE on source tokens (label 0) + mean BCE on target tokens (label 1);
   * loss_proto_da: BCE masked by class presence but averaged over all 2C entries;
   * loss_contrast_da: cross-entropy with soft (masked identity) targets on cosine logits.
+
+Differences from the reference that do not change values: prediction sets of identical shape
+(final + 5 auxiliary + two-stage; the 6 de-noising sets) are evaluated as one batched family
+(`_family_losses`) -- one fused focal-loss launch, pair-wise GIoU, ONE device->host copy for all
+7 Hungarian cost matrices (`HungarianMatcher.forward_many`) instead of 7.  The reference's
+degenerate-box asserts (box_ops.py:52-53) remain in the matcher; inside the loss they are
+redundant for matched sets (same boxes) and a NaN box trips the engine's non-finite guard.
+`loss_labels` / `loss_boxes` / `loss_cardinality` / `get_loss` keep the reference's per-set API.
 """
 from __future__ import annotations
 
@@ -19,6 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import boxes as box_ops
+from .focal import sigmoid_focal_loss_sums as focal_loss_sums
 from .nested import accuracy, get_world_size, is_dist_avail_and_initialized
 
 
@@ -152,22 +161,107 @@ class SetCriterion(nn.Module):
         return {k + suffix: z() for k in ("loss_bbox_dn", "loss_giou_dn", "loss_ce_dn", "loss_xy_dn",
                                           "loss_hw_dn", "cardinality_error_dn")}
 
+    def _family_losses(self, outs, targets, indices_per_out, num_boxes, log_first):
+        """All requested losses for a FAMILY of prediction sets with identical shapes (e.g. the
+        final + auxiliary + two-stage outputs, or the de-noising outputs of every layer) in one
+        batched evaluation.  Same arithmetic per element as get_loss() on each set; the focal
+        term runs in the fused HIP kernel (datr_amd.focal), the matched-pair GIoU is evaluated
+        pair-wise instead of as the diagonal of an n x n matrix (dino.py:563-565).
+        Returns one dict per set, keys in the reference's creation order."""
+        G = len(outs)
+        logits = torch.stack([o["pred_logits"] for o in outs])          # [G, B, Q, C]
+        boxes = torch.stack([o["pred_boxes"] for o in outs])            # [G, B, Q, 4]
+        _, B, Q, C = logits.shape
+        device = logits.device
+        counts = [len(t["labels"]) for t in targets]
+        offsets = [0]
+        for c in counts:
+            offsets.append(offsets[-1] + c)
+        labels_cat = torch.cat([t["labels"] for t in targets])
+        boxes_cat = torch.cat([t["boxes"] for t in targets])
+        gi, bi, qi, ti = [], [], [], []
+        for g, indices in enumerate(indices_per_out):
+            for b, (src, tgt) in enumerate(indices):
+                n = src.numel()
+                if n == 0:
+                    continue
+                gi.append(torch.full((n,), g, dtype=torch.int64, device=src.device))
+                bi.append(torch.full((n,), b, dtype=torch.int64, device=src.device))
+                qi.append(src)
+                ti.append(tgt + offsets[b])
+        if gi:
+            packed = torch.stack([torch.cat(gi), torch.cat(bi), torch.cat(qi), torch.cat(ti)])
+            packed = packed.to(device, non_blocking=True)
+            g_idx, b_idx, q_idx, t_idx = packed[0], packed[1], packed[2], packed[3]
+        else:
+            g_idx = b_idx = q_idx = t_idx = torch.zeros(0, dtype=torch.int64, device=device)
+
+        res = [dict() for _ in range(G)]
+        zeros_g = lambda: torch.zeros(G, dtype=logits.dtype, device=device)
+        for loss in self.losses:
+            if loss == "labels":
+                matched_cls = labels_cat[t_idx]
+                target_classes = torch.full((G, B, Q), self.num_classes, dtype=torch.int64, device=device)
+                target_classes[g_idx, b_idx, q_idx] = matched_cls
+                sums = focal_loss_sums(logits.reshape(G, B * Q, C), target_classes.view(G, B * Q),
+                                       self.focal_alpha, 2.0)
+                loss_ce = sums / Q / num_boxes * Q
+                for g in range(G):
+                    res[g]["loss_ce"] = loss_ce[g]
+                if log_first:
+                    first = g_idx == 0
+                    res[0]["class_error"] = 100 - accuracy(
+                        logits[0][b_idx[first], q_idx[first]], matched_cls[first])[0]
+            elif loss == "boxes":
+                src = boxes[g_idx, b_idx, q_idx]
+                tgt = boxes_cat[t_idx]
+                l1 = F.l1_loss(src, tgt, reduction="none")
+                giou = box_ops.generalized_box_iou_pairs(box_ops.box_cxcywh_to_xyxy(src),
+                                                         box_ops.box_cxcywh_to_xyxy(tgt))
+                per_g = lambda v: zeros_g().index_add_(0, g_idx, v)
+                loss_bbox = per_g(l1.sum(-1)) / num_boxes
+                loss_giou = per_g(1 - giou) / num_boxes
+                with torch.no_grad():
+                    loss_xy = per_g(l1[..., :2].sum(-1)) / num_boxes
+                    loss_hw = per_g(l1[..., 2:].sum(-1)) / num_boxes
+                for g in range(G):
+                    res[g]["loss_bbox"], res[g]["loss_giou"] = loss_bbox[g], loss_giou[g]
+                    res[g]["loss_xy"], res[g]["loss_hw"] = loss_xy[g], loss_hw[g]
+            elif loss == "cardinality":
+                with torch.no_grad():
+                    lengths = torch.as_tensor(counts, device=device).float()
+                    card_pred = (logits.argmax(-1) != C - 1).sum(-1).float()         # [G, B]
+                    card_err = (card_pred - lengths[None]).abs().mean(-1)
+                for g in range(G):
+                    res[g]["cardinality_error"] = card_err[g]
+            else:
+                raise AssertionError(f"do you really want to compute {loss} loss?")
+        return res
+
     def forward(self, outputs, targets, return_indices=False, target_domain_flag=False):
+        sfx = "_target" if target_domain_flag else ""
         if target_domain_flag:
-            outputs_without_aux = {k.replace("_target", ""): v for k, v in outputs.items()
-                                   if k != "aux_outputs_target"}
             outputs.update({"pred_boxes": outputs.pop("pred_boxes_target")})
             outputs.update({"pred_logits": outputs.pop("pred_logits_target")})
             device = outputs["pred_logits"].device
         else:
-            outputs_without_aux = {k: v for k, v in outputs.items() if k != "aux_outputs"}
             device = next(iter(outputs.values())).device
 
+        # every prediction set that gets matched: final, auxiliary layers, two-stage, encoder
+        final = {"pred_logits": outputs["pred_logits"], "pred_boxes": outputs["pred_boxes"]}
+        aux = list(outputs.get("aux_outputs" + sfx, []))
+        interm = outputs.get("interm_outputs" + sfx)
+        enc = list(outputs.get("enc_outputs" + sfx, []))
+        matched = [final] + aux + ([interm] if interm is not None else []) + enc
+
         if len(targets) > 0:
-            indices = self.matcher(outputs_without_aux, targets)
+            same = all(o["pred_logits"].shape == final["pred_logits"].shape for o in matched)
+            if same:
+                all_indices = self.matcher.forward_many(matched, targets)
+            else:
+                all_indices = [self.matcher(o, targets) for o in matched]
+            indices = all_indices[0]
             num_boxes = float(sum(len(t["labels"]) for t in targets))
-            if return_indices:
-                indices0_copy, indices_list = indices, []
         else:           # no pseudo labels on this rank: keep the collective below in lock-step
             indices, num_boxes = None, 1.0
 
@@ -184,7 +278,19 @@ class SetCriterion(nn.Module):
         if indices is None:
             return {}
 
+        if all(o["pred_logits"].shape == final["pred_logits"].shape for o in matched):
+            fam = self._family_losses(matched, targets, all_indices, num_boxes,
+                                      log_first=not target_domain_flag)
+        else:
+            fam = [self._family_losses([o], targets, [idx], num_boxes,
+                                       log_first=(i == 0 and not target_domain_flag))[0]
+                   for i, (o, idx) in enumerate(zip(matched, all_indices))]
+        final_l, aux_l = fam[0], fam[1:1 + len(aux)]
+        interm_l = fam[1 + len(aux)] if interm is not None else None
+        enc_l = fam[len(fam) - len(enc):] if enc else []
+
         losses = {}
+        use_dn = False
         if not target_domain_flag:
             dn_meta = outputs["dn_meta"]
             use_dn = bool(self.training and dn_meta and "output_known_lbs_bboxes" in dn_meta)
@@ -192,62 +298,28 @@ class SetCriterion(nn.Module):
                 known = dn_meta["output_known_lbs_bboxes"]
                 groups, pad_size = dn_meta["num_dn_group"], dn_meta["pad_size"]
                 assert pad_size % groups == 0
-                single_pad = pad_size // groups
-                dn_pos_idx, _ = self._dn_indices(targets, single_pad, groups, device)
-                l_dict = {}
-                for loss in self.losses:
-                    kwargs = {"log": False} if "labels" in loss else {}
-                    l_dict.update(self.get_loss(loss, known, targets, dn_pos_idx,
-                                                num_boxes * groups, **kwargs))
-                losses.update({k + "_dn": v for k, v in l_dict.items()})
+                dn_pos_idx, _ = self._dn_indices(targets, pad_size // groups, groups, device)
+                dn_sets = [{"pred_logits": known["pred_logits"], "pred_boxes": known["pred_boxes"]}]
+                dn_sets += list(known.get("aux_outputs", []))
+                dn_l = self._family_losses(dn_sets, targets, [dn_pos_idx] * len(dn_sets),
+                                           num_boxes * groups, log_first=False)
+                losses.update({k + "_dn": v for k, v in dn_l[0].items()})
             else:
                 losses.update(self._zero_dn(device))
-            for loss in self.losses:
-                losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
+            losses.update(final_l)
 
-        key_aux = "aux_outputs_target" if target_domain_flag else "aux_outputs"
-        if key_aux in outputs:
-            for idx, aux_outputs in enumerate(outputs[key_aux]):
-                indices = self.matcher(aux_outputs, targets)
-                if return_indices:
-                    indices_list.append(indices)
-                for loss in self.losses:
-                    kwargs = {"log": False} if loss == "labels" else {}
-                    l_dict = self.get_loss(loss, aux_outputs, targets, indices, num_boxes, **kwargs)
-                    losses.update({k + f"_{idx}": v for k, v in l_dict.items()})
-                if not target_domain_flag:
-                    if use_dn:
-                        aux_known = known["aux_outputs"][idx]
-                        l_dict = {}
-                        for loss in self.losses:
-                            kwargs = {"log": False} if "labels" in loss else {}
-                            l_dict.update(self.get_loss(loss, aux_known, targets, dn_pos_idx,
-                                                        num_boxes * groups, **kwargs))
-                        losses.update({k + f"_dn_{idx}": v for k, v in l_dict.items()})
-                    else:
-                        losses.update(self._zero_dn(device, f"_{idx}"))
-
-        key_interm = "interm_outputs_target" if target_domain_flag else "interm_outputs"
-        if key_interm in outputs:
-            interm = outputs[key_interm]
-            indices = self.matcher(interm, targets)
-            if return_indices:
-                indices_list.append(indices)
-            for loss in self.losses:
-                kwargs = {"log": False} if loss == "labels" else {}
-                l_dict = self.get_loss(loss, interm, targets, indices, num_boxes, **kwargs)
-                losses.update({k + "_interm": v for k, v in l_dict.items()})
-
-        key_enc = "enc_outputs_target" if target_domain_flag else "enc_outputs"
-        if key_enc in outputs:
-            for i, enc_outputs in enumerate(outputs[key_enc]):
-                indices = self.matcher(enc_outputs, targets)
-                if return_indices:
-                    indices_list.append(indices)
-                for loss in self.losses:
-                    kwargs = {"log": False} if loss == "labels" else {}
-                    l_dict = self.get_loss(loss, enc_outputs, targets, indices, num_boxes, **kwargs)
-                    losses.update({k + f"_enc_{i}": v for k, v in l_dict.items()})
+        for idx, l_dict in enumerate(aux_l):
+            l_dict = {k: v for k, v in l_dict.items() if k != "class_error"}
+            losses.update({k + f"_{idx}": v for k, v in l_dict.items()})
+            if not target_domain_flag:
+                if use_dn:
+                    losses.update({k + f"_dn_{idx}": v for k, v in dn_l[1 + idx].items()})
+                else:
+                    losses.update(self._zero_dn(device, f"_{idx}"))
+        if interm_l is not None:
+            losses.update({k + "_interm": v for k, v in interm_l.items() if k != "class_error"})
+        for i, l_dict in enumerate(enc_l):
+            losses.update({k + f"_enc_{i}": v for k, v in l_dict.items() if k != "class_error"})
 
         if "da_output" in outputs:
             da = outputs["da_output"]
@@ -256,6 +328,6 @@ class SetCriterion(nn.Module):
             losses["loss_global_proto_DA"] = self.loss_contrast_da(da["global_proto_DA"])
 
         if return_indices:
-            indices_list.append(indices0_copy)
-            return losses, indices_list
+            # reference order: auxiliary layers, two-stage, (encoder), then the final layer
+            return losses, all_indices[1:] + [all_indices[0]]
         return losses

@@ -138,12 +138,20 @@ class DINO(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _heads(self, hs, reference):
-        """Per decoder layer: boxes = sigmoid(delta + logit(reference)), class logits."""
-        coords = []
-        for layer_ref, box_head, layer_hs in zip(reference[:-1], self.bbox_embed, hs):
-            coords.append((box_head(layer_hs) + inverse_sigmoid(layer_ref)).sigmoid())
-        coords = torch.stack(coords)
-        classes = torch.stack([cls_head(layer_hs) for cls_head, layer_hs in zip(self.class_embed, hs)])
+        """Per decoder layer: boxes = sigmoid(delta + logit(reference)), class logits.
+        When the per-layer heads alias one module (dec_pred_*_embed_share, dino.py:155-166) all
+        layers go through it as ONE batched call -- same weights, same arithmetic per row."""
+        n = len(hs)
+        hs_all = torch.stack(list(hs))                               # [n_dec, B, Q, d]
+        if all(m is self.bbox_embed[0] for m in self.bbox_embed[:n]):
+            delta = self.bbox_embed[0](hs_all)
+        else:
+            delta = torch.stack([h(x) for h, x in zip(self.bbox_embed, hs)])
+        coords = (delta + inverse_sigmoid(torch.stack(list(reference[:-1])))).sigmoid()
+        if all(m is self.class_embed[0] for m in self.class_embed[:n]):
+            classes = self.class_embed[0](hs_all)
+        else:
+            classes = torch.stack([h(x) for h, x in zip(self.class_embed, hs)])
         return classes, coords
 
     @torch.jit.unused

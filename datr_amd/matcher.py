@@ -58,6 +58,21 @@ class HungarianMatcher(nn.Module):
         sizes = [len(v["boxes"]) for v in targets]
         return [solve_lsap(c[i]) for i, c in enumerate(C.split(sizes, -1))]
 
+    @torch.no_grad()
+    def forward_many(self, outputs_list, targets):
+        """Match several prediction sets of identical shape (the final layer, the auxiliary
+        layers, the two-stage output) against the same targets: the G cost matrices are built by
+        one batched evaluation and cross to the host in ONE copy (the reference pays a
+        device->host sync per set, matcher.py:91, i.e. 7 per step).  Returns a list (per set) of
+        the per-image (row_idx, col_idx) pairs -- identical to calling forward() on each."""
+        G = len(outputs_list)
+        bs, nq = outputs_list[0]["pred_logits"].shape[:2]
+        stacked = {"pred_logits": torch.cat([o["pred_logits"] for o in outputs_list], 0),
+                   "pred_boxes": torch.cat([o["pred_boxes"] for o in outputs_list], 0)}
+        C = self.cost_matrix(stacked, targets).view(G, bs, nq, -1).cpu()
+        sizes = [len(v["boxes"]) for v in targets]
+        return [[solve_lsap(c[i]) for i, c in enumerate(C[g].split(sizes, -1))] for g in range(G)]
+
 
 def build_matcher(args):
     if args.matcher_type != "HungarianMatcher":

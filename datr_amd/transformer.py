@@ -205,7 +205,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_sa(self, tgt, query_pos, attn_mask):
         q = k = tgt if query_pos is None else tgt + query_pos
-        tgt2 = self.self_attn(q, k, tgt, attn_mask=attn_mask)[0]
+        tgt2 = self.self_attn(q, k, tgt, attn_mask=attn_mask, need_weights=False)[0]
         return self.norm2(tgt + self.dropout2(tgt2))
 
     def forward_ca(self, tgt, query_pos, reference_points, memory, spatial_shapes,

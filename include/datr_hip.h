@@ -103,6 +103,31 @@ int datr_msda_backward_f64(const double *grad_out, const double *value, const in
  * 1 = row-vectorised gfx950 fast path, 0 = generic one-thread-per-scalar path. */
 int datr_msda_uses_fast_path(int64_t S, int64_t M, int64_t D, int64_t L, int64_t P);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused sigmoid focal loss (classification loss of SetCriterion).
+ *
+ * Replaces `sigmoid_focal_loss` (/root/reference/models/dino/utils.py:79-104) together with the
+ * one-hot construction in `SetCriterion.loss_labels` (/root/reference/models/dino/dino.py:517-526).
+ *   logits  [G, R, C] fp32      G independent groups (e.g. decoder layers), R rows (= B*Q) each
+ *   target  [G, R]    int64     matched class index per row; any value outside [0, C) (the
+ *                               reference uses num_classes) means "no positive in this row"
+ *   out_sums[G]                 sum over the group's R*C elements of
+ *                               alpha_t * BCEWithLogits(x, t) * (1 - p_t)^gamma
+ *                               (alpha < 0 disables the alpha_t factor, as in the reference)
+ * The reference's normalisation `.mean(1).sum() / num_boxes * num_queries` equals
+ * out_sums / num_boxes and is left to the caller.
+ * `scratch` must hold datr_focal_scratch_floats(G, R) floats; sums are folded in a fixed order
+ * (bitwise reproducible).  backward: grad_logits[g,r,c] = grad_sums[g] * d loss/d x.
+ * ------------------------------------------------------------------------------------------ */
+int64_t datr_focal_scratch_floats(int64_t G, int64_t rows_per_group);
+int datr_focal_loss_forward_f32(const float *logits, const int64_t *target, int64_t G,
+                                int64_t rows_per_group, int64_t C, float alpha, float gamma,
+                                float *scratch, float *out_sums, void *stream);
+int datr_focal_loss_backward_f32(const float *logits, const int64_t *target,
+                                 const float *grad_sums, int64_t G, int64_t rows_per_group,
+                                 int64_t C, float alpha, float gamma, float *grad_logits,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

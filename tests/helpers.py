@@ -51,6 +51,10 @@ def patch_msda_with_oracle(monkeypatch, kind="c"):
 
     monkeypatch.setattr(msda, "ms_deform_attn_forward", fwd)
     monkeypatch.setattr(msda, "ms_deform_attn_backward", bwd)
+    # the fused focal-loss kernel has no CPU path either: stand in the reference's formulation
+    from datr_amd import criterion
+    from oracle import focal_oracle
+    monkeypatch.setattr(criterion, "focal_loss_sums", focal_oracle.focal_sums_torch)
 
 
 def build_model(device="cpu"):

@@ -64,11 +64,17 @@ def _worker(rank, world, port, tmp):
             for p in b.params:
                 assert p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
     # criterion: num_boxes is the world average of the per-rank counts, clamped at 1
+    from datr_amd import criterion as crit_mod
     from datr_amd.criterion import SetCriterion
+    from oracle import focal_oracle
+    crit_mod.focal_loss_sums = focal_oracle.focal_sums_torch      # no GPU in this test
 
     class M(nn.Module):
         def forward(self, outputs, targets):
             return [(torch.arange(len(t["labels"])), torch.arange(len(t["labels"]))) for t in targets]
+
+        def forward_many(self, outs, targets):
+            return [self.forward(o, targets) for o in outs]
     crit = SetCriterion(3, M(), {}, 0.25, ["labels", "boxes", "cardinality"])
     n_gt = 1 if rank == 0 else 3
     out = {"pred_logits": torch.zeros(1, 5, 3), "pred_boxes": torch.full((1, 5, 4), 0.5),
