@@ -68,8 +68,10 @@ class Trainer:
         self.model.to(device)
         self.model.train()
         self.criterion.train()
+        # same update rule as the reference's AdamW (main.py:162-165); `fused` only selects
+        # PyTorch's single-kernel multi-tensor implementation of it
         self.optimizer = torch.optim.AdamW(get_param_dict(self.cfg, self.model), lr=self.cfg.lr,
-                                           weight_decay=self.cfg.weight_decay)
+                                           weight_decay=self.cfg.weight_decay, fused=True)
         self.reducer = GradAllReducer(self.model) if distributed or args.flat_grads else None
         self.max_norm = self.cfg.clip_max_norm
 

@@ -74,6 +74,9 @@ class DINO(nn.Module):
         self.register_buffer("Amount", torch.zeros(num_classes), persistent=False)
         self.Proto_D = MLP(hidden_dim, hidden_dim, 1, 3)
         self.domain_adaptation = True
+        # one encoder call for source+target (same values up to fp32 GEMM blocking); False
+        # reproduces the reference's two separate transformer calls exactly
+        self.merge_encoder_passes = True
         self.dn_noise_override = None        # tests inject the reference's RNG draws here
 
         if num_feature_levels > 1:
@@ -192,8 +195,20 @@ class DINO(nn.Module):
             assert targets is None
             input_query_bbox = input_query_label = attn_mask = dn_meta = None
 
-        hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer(
-            srcs, masks, input_query_bbox, poss, input_query_label, attn_mask)
+        merged = da and self.merge_encoder_passes
+        if merged:
+            # the encoder is per-sample: run it ONCE on all 2B images (the reference runs it
+            # separately for the source and the target half, dino.py:291,380 -- same values,
+            # half the launches, larger GEMMs), then decode each half on its own
+            enc_all = self.transformer.encode(srcs_all, masks_all, poss_all)
+            half = srcs_all[0].shape[0] // 2
+            enc_src = self.transformer.slice_encoded(enc_all, slice(0, half))
+            enc_tgt = self.transformer.slice_encoded(enc_all, slice(half, None))
+            hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer.decode(
+                enc_src, input_query_bbox, input_query_label, attn_mask)
+        else:
+            hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer(
+                srcs, masks, input_query_bbox, poss, input_query_label, attn_mask)
         hs[0] = hs[0] + self.label_enc.weight[0, 0] * 0.0
 
         outputs_class, outputs_coord_list = self._heads(hs, reference)
@@ -225,8 +240,12 @@ class DINO(nn.Module):
             self.global_proto, self.Amount = g_proto, g_amount
 
             # second transformer pass: target half, no DN queries, no attention mask
-            hs_t, reference_t, hs_enc_t, ref_enc_t, init_box_proposal_t = self.transformer(
-                srcs_target, masks_target, None, poss_target, None, None)
+            if merged:
+                hs_t, reference_t, hs_enc_t, ref_enc_t, init_box_proposal_t = \
+                    self.transformer.decode(enc_tgt, None, None, None)
+            else:
+                hs_t, reference_t, hs_enc_t, ref_enc_t, init_box_proposal_t = self.transformer(
+                    srcs_target, masks_target, None, poss_target, None, None)
             out_t = hs_t[-1]
             proto_t, present_t, g_proto, g_amount, _ = get_prototype_class_wise(
                 out_t, self.class_embed[-1](out_t), self.num_classes,

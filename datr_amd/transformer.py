@@ -419,7 +419,9 @@ class DeformableTransformer(nn.Module):
             hit = self._meta_cache[key] = (spatial_shapes, level_start_index)
         return hit
 
-    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None):
+    def encode(self, srcs, masks, pos_embeds):
+        """Flatten the pyramid and run the deformable encoder.  Every encoder operation is
+        per-sample, so the source and target halves of a DATR batch can share one call."""
         src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes_list = [], [], [], []
         for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
             bs, c, h, w = src.shape
@@ -435,11 +437,28 @@ class DeformableTransformer(nn.Module):
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
         spatial_shapes, level_start_index = self._level_meta(shapes_list, src_flatten.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
-
         memory, _, _ = self.encoder(src_flatten, pos=lvl_pos_embed_flatten,
                                     level_start_index=level_start_index,
                                     spatial_shapes=spatial_shapes, valid_ratios=valid_ratios,
                                     key_padding_mask=mask_flatten, shapes_list=shapes_list)
+        return {"memory": memory, "mask": mask_flatten, "pos": lvl_pos_embed_flatten,
+                "shapes_list": shapes_list, "spatial_shapes": spatial_shapes,
+                "level_start_index": level_start_index, "valid_ratios": valid_ratios}
+
+    @staticmethod
+    def slice_encoded(enc, sl):
+        """The batch slice `sl` of an encode() result (e.g. the source or the target half)."""
+        out = dict(enc)
+        for k in ("memory", "mask", "pos", "valid_ratios"):
+            out[k] = enc[k][sl]
+        return out
+
+    def decode(self, enc, refpoint_embed, tgt, attn_mask=None):
+        """Two-stage query selection + decoder on an encode() result."""
+        memory, mask_flatten, lvl_pos_embed_flatten = enc["memory"], enc["mask"], enc["pos"]
+        shapes_list, spatial_shapes = enc["shapes_list"], enc["spatial_shapes"]
+        level_start_index, valid_ratios = enc["level_start_index"], enc["valid_ratios"]
+        bs = memory.shape[0]
 
         if self.two_stage_type == "standard":
             input_hw = self.two_stage_wh_embedding.weight[0] if self.two_stage_learn_wh else None
@@ -487,6 +506,10 @@ class DeformableTransformer(nn.Module):
         else:
             hs_enc = ref_enc = None
         return hs, references, hs_enc, ref_enc, init_box_proposal
+
+    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None):
+        """Reference signature (deformable_transformer.py:256): encoder, selection, decoder."""
+        return self.decode(self.encode(srcs, masks, pos_embeds), refpoint_embed, tgt, attn_mask)
 
 
 def build_deformable_transformer(args):

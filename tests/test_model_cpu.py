@@ -103,11 +103,27 @@ def test_full_training_step_matches_reference(monkeypatch):
     patch_msda_with_oracle(monkeypatch, kind="grid_sample")
     g = load_npz("model_step.npz")
     _, model, criterion, _ = build_model()
+    model.merge_encoder_passes = False       # the reference's call structure: bit-identical
     out, loss_dict, indices_list, total = run_training_step(model, criterion, "cpu", g)
     assert len(loss_dict) == 82
     # same arithmetic as the reference's CPU path -> far tighter than the 1e-3 contract
     check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-5, loss_rtol=1e-5)
     check_gradients(model, g, rtol=1e-4)
+
+
+def test_merged_encoder_pass_matches_reference(monkeypatch):
+    """Default mode: ONE encoder call for the source and target halves.  Values agree with the
+    reference to fp32 rounding; with the top-900 selection pinned (the forward's one
+    discontinuity, see tests/test_model_gpu.py) the whole step agrees element-wise."""
+    from helpers import force_reference_selection
+    patch_msda_with_oracle(monkeypatch, kind="grid_sample")
+    g = load_npz("model_step.npz")
+    _, model, criterion, _ = build_model()
+    assert model.merge_encoder_passes
+    force_reference_selection(model, g, "cpu")
+    out, loss_dict, indices_list, total = run_training_step(model, criterion, "cpu", g)
+    check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-4, loss_rtol=1e-4)
+    check_gradients(model, g, rtol=1e-3)
 
 
 def test_eval_forward_and_postprocess(monkeypatch):
