@@ -63,6 +63,9 @@ class Trainer:
         from datr_amd.detector import build_dino
         from datr_amd.dist import GradAllReducer
         self.cfg = c2f_args(device=str(device))
+        if getattr(args, "tuned_gemm", True):
+            from datr_amd import tuning
+            tuning.enable()          # per-shape hipBLASLt kernel selection, lookup only
         torch.manual_seed(0)
         self.model, self.criterion, _ = build_dino(self.cfg)
         self.model.to(device)
@@ -189,6 +192,8 @@ def main():
     ap.add_argument("--num-gt", type=int, default=10)
     ap.add_argument("--flat-grads", action="store_true", help="use the flat-bucket reducer at N=1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tuned-gemm", dest="tuned_gemm", action="store_false",
+                    help="leave hipBLASLt on its default heuristic (datr_amd/tuning)")
     args = ap.parse_args()
 
     from datr_amd.dist import init_distributed

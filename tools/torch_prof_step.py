@@ -6,7 +6,9 @@ import bench
 from torch.profiler import profile, ProfilerActivity
 
 ap = argparse.ArgumentParser(); ap.add_argument("--rows", type=int, default=60); a = ap.parse_args()
-class A: flat_grads = False
+class A:
+    flat_grads = False
+    tuned_gemm = True
 dev = torch.device("cuda:0")
 tr = bench.Trainer(A, dev, distributed=False)
 samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
