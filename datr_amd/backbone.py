@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .fused import frozen_bn_act
 from .nested import NestedTensor
 
 
@@ -41,9 +42,18 @@ class FrozenBatchNorm2d(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
                                       unexpected_keys, error_msgs)
 
+    @torch.no_grad()
     def scale_shift(self):
-        scale = self.weight * (self.running_var + 1e-5).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, shift) of the equivalent per-channel affine; cached until a buffer changes
+        (load_state_dict, .to(device)) so a training step does not recompute 53 x 4 tiny ops."""
+        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((b.data_ptr(), b._version) for b in bufs)
+        cache = getattr(self, "_affine_cache", None)
+        if cache is None or cache[0] != key:
+            scale = self.weight * (self.running_var + 1e-5).rsqrt()
+            cache = (key, scale, self.bias - self.running_mean * scale)
+            object.__setattr__(self, "_affine_cache", cache)
+        return cache[1], cache[2]
 
     def forward(self, x):
         scale, shift = self.scale_shift()
@@ -69,11 +79,21 @@ class Bottleneck(nn.Module):
                 norm_layer(planes * 4))
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        if not isinstance(self.bn1, FrozenBatchNorm2d):       # foreign norm layer: plain path
+            identity = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.relu(self.bn2(self.conv2(out)))
+            return self.relu(self.bn3(self.conv3(out)) + identity)
+        # frozen BN = per-channel affine: fold it with the ReLU / residual that follows into one
+        # pass over the activation (datr_amd.fused.frozen_bn_act)
+        if self.downsample is None:
+            identity = x
+        else:
+            identity = frozen_bn_act(self.downsample[0](x), *self.downsample[1].scale_shift(),
+                                     relu=False)
+        out = frozen_bn_act(self.conv1(x), *self.bn1.scale_shift(), relu=True)
+        out = frozen_bn_act(self.conv2(out), *self.bn2.scale_shift(), relu=True)
+        return frozen_bn_act(self.conv3(out), *self.bn3.scale_shift(), residual=identity, relu=True)
 
 
 class ResNet50Body(nn.Module):
@@ -98,8 +118,13 @@ class ResNet50Body(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
+    def stem(self, x):
+        if isinstance(self.bn1, FrozenBatchNorm2d):
+            return frozen_bn_act(self.conv1(x), *self.bn1.scale_shift(), relu=True)
+        return self.relu(self.bn1(self.conv1(x)))
+
     def forward(self, x):                      # plain classifier-less trunk
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.stem(x))
         for i in range(1, 5):
             x = getattr(self, f"layer{i}")(x)
         return x
@@ -122,10 +147,21 @@ class _StageOutputs(nn.ModuleDict):
 
     def forward(self, x):
         out = OrderedDict()
-        for name, child in self.items():
+        items = list(self.items())
+        i = 0
+        while i < len(items):
+            name, child = items[i]
+            if (name == "conv1" and i + 2 < len(items)
+                    and isinstance(items[i + 1][1], FrozenBatchNorm2d)
+                    and isinstance(items[i + 2][1], nn.ReLU)):
+                # stem: conv -> frozen BN -> ReLU as conv + one fused pass
+                x = frozen_bn_act(child(x), *items[i + 1][1].scale_shift(), relu=True)
+                i += 3
+                continue
             x = child(x)
             if name in self.return_layers:
                 out[self.return_layers[name]] = x
+            i += 1
         return out
 
 

@@ -63,7 +63,7 @@ constexpr int kWaves = kThreads / 64;
 static_assert(kWaves <= 16, "fctl holds 16 per-wave partials per quantity");
 constexpr int kLPR = 8;                 // lanes per 32-channel row (float4 each)
 constexpr int kGroups = kThreads / kLPR;
-constexpr int kTW = DATR_TILE_W, kTH = DATR_TILE_H, kTQ = kTW * kTH;
+constexpr int kTW = DATR_TILE_W, kTH = DATR_TILE_H;
 constexpr int kWinRows = 480;           // rows (x 32 ch x 4 B = 60 KB) of the accumulation window
 constexpr int kMaxPairs = 512;          // kTQ * P with P <= 4
 constexpr unsigned kOutOfRange = 0x80000000u;

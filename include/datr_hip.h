@@ -128,6 +128,24 @@ int datr_focal_loss_backward_f32(const float *logits, const int64_t *target,
                                  int64_t C, float alpha, float gamma, float *grad_logits,
                                  void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused frozen batch-norm (+ residual) (+ ReLU) of the ResNet-50 trunk.
+ *
+ * Replaces `FrozenBatchNorm2d.forward` (/root/reference/models/dino/backbone.py:62-72: two
+ * element-wise kernels) and the ReLU / residual-add that follow it in torchvision's Bottleneck.
+ *   y[i] = act( x[i] * scale[c] + shift[c] (+ res[i]) ),   c = (i / inner) % C
+ * `inner` = H*W for NCHW tensors, 1 for NHWC; `res` may be NULL; `relu` != 0 applies max(.,0).
+ * scale = weight * rsqrt(running_var + 1e-5), shift = bias - running_mean * scale are computed
+ * by the caller (they are buffers, not parameters).
+ * backward: g = dy * (y > 0 if relu); dx = g * scale[c]; dres = g (if dres != NULL).
+ * ------------------------------------------------------------------------------------------ */
+int datr_affine_act_forward_f32(const float *x, const float *res, const float *scale,
+                                const float *shift, int64_t n, int64_t C, int64_t inner, int relu,
+                                float *y, void *stream);
+int datr_affine_act_backward_f32(const float *dy, const float *y, const float *scale, int64_t n,
+                                 int64_t C, int64_t inner, int relu, float *dx, float *dres,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

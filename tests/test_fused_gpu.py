@@ -1,0 +1,57 @@
+"""GPU: fused frozen-BN (+residual) (+ReLU) kernel against the reference's op-by-op formula
+(/root/reference/models/dino/backbone.py:62-72 followed by add / relu)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def reference(x, w, b, rm, rv, res, relu):
+    scale = w * (rv + 1e-5).rsqrt()
+    y = x * scale.view(1, -1, 1, 1) + (b - rm * scale).view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 50, 84), (1, 2048, 25, 42), (3, 7, 5, 3), (4, 256, 8, 8)])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_frozen_bn_act(shape, relu, with_res):
+    from datr_amd.backbone import FrozenBatchNorm2d
+    from datr_amd.fused import frozen_bn_act
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    bn = FrozenBatchNorm2d(C)
+    bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.bias.copy_(torch.randn(C, generator=g))
+    bn.running_mean.copy_(torch.randn(C, generator=g))
+    bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.to(dev)
+    x = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+    res = torch.randn(shape, generator=g).to(dev).requires_grad_(True) if with_res else None
+    go = torch.randn(shape, generator=g).to(dev)
+    y = frozen_bn_act(x, *bn.scale_shift(), residual=res, relu=relu)
+    y.backward(go)
+    gx, gr = x.grad.clone(), None if res is None else res.grad.clone()
+    x.grad = None
+    if res is not None:
+        res.grad = None
+    yr = reference(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu)
+    yr.backward(go)
+    torch.testing.assert_close(y, yr, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gx, x.grad, rtol=1e-6, atol=1e-6)
+    if res is not None:
+        torch.testing.assert_close(gr, res.grad, rtol=0, atol=0)
+
+
+def test_scale_shift_cache_invalidates_on_load():
+    from datr_amd.backbone import FrozenBatchNorm2d
+    bn = FrozenBatchNorm2d(4).cuda()
+    s1, _ = bn.scale_shift()
+    assert bn.scale_shift()[0] is s1                       # cached
+    bn.load_state_dict({"weight": torch.full((4,), 2.0), "bias": torch.zeros(4),
+                        "running_mean": torch.zeros(4), "running_var": torch.ones(4)})
+    s2, _ = bn.scale_shift()
+    torch.testing.assert_close(s2, torch.full((4,), 2.0, device="cuda") / (1 + 1e-5) ** 0.5)
