@@ -69,6 +69,8 @@ class Trainer:
         torch.manual_seed(0)
         self.model, self.criterion, _ = build_dino(self.cfg)
         self.model.to(device)
+        if getattr(args, "channels_last", False):
+            self.model.backbone.to(memory_format=torch.channels_last)
         self.model.train()
         self.criterion.train()
         # same update rule as the reference's AdamW (main.py:162-165); `fused` only selects
@@ -129,9 +131,19 @@ class MsdaTimer:
         N, S, M, D, K, Lq = self.shape
         algo_bytes = 4 * N * (S * M * D + Lq * M * K * 3 + Lq * M * D)
         mean_us = sum(us) / len(us)
+        # HBM traffic per launch from the PMC passes committed under profiles/ (same kernel,
+        # N=2 shape; FETCH_SIZE corrected as the micro-architecture guide prescribes); scales
+        # linearly with N for the merged source+target encoder call
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc.json")
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            sh = rec["shape"]
+            if (sh["S"], sh["M"], sh["D"], sh["Lq"]) == (S, M, D, Lq) and sh["L"] * sh["P"] == K:
+                traffic = int(rec["traffic_bytes"] * N / sh["N"])
         achieved = algo_bytes / mean_us / 1e3
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel": "msda_fwd_rows<8,16> (encoder call)", "launches": len(us),
                 "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
 
@@ -192,6 +204,7 @@ def main():
     ap.add_argument("--num-gt", type=int, default=10)
     ap.add_argument("--flat-grads", action="store_true", help="use the flat-bucket reducer at N=1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC backbone")
     ap.add_argument("--no-tuned-gemm", dest="tuned_gemm", action="store_false",
                     help="leave hipBLASLt on its default heuristic (datr_amd/tuning)")
     args = ap.parse_args()
@@ -206,6 +219,8 @@ def main():
     trainer = Trainer(args, device, distributed=world > 1)
     samples, targets = synthetic_batch(args.batch, args.height, args.width, args.num_gt, device,
                                        seed=1 + rank)
+    if args.channels_last:
+        samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
     timer = MsdaTimer()
     timer.install()
 

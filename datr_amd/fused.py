@@ -13,30 +13,35 @@ class _AffineAct(Function):
 
     @staticmethod
     def forward(ctx, x, scale, shift, res, relu):
-        x = x.contiguous()
         N, C, H, W = x.shape
-        y = torch.empty_like(x)
+        # NHWC (channels_last) tensors are processed in place of layout: channel = i % C
+        nhwc = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        x = x.contiguous(memory_format=fmt)
+        y = torch.empty_like(x, memory_format=fmt)
         if res is not None:
-            res = res.contiguous()
+            res = res.contiguous(memory_format=fmt)
+        inner = 1 if nhwc else H * W
         with torch.cuda.device(x.device):
             rc = _native.lib.datr_affine_act_forward_f32(
                 x.data_ptr(), 0 if res is None else res.data_ptr(), scale.data_ptr(),
-                shift.data_ptr(), x.numel(), C, H * W, int(relu), y.data_ptr(),
+                shift.data_ptr(), x.numel(), C, inner, int(relu), y.data_ptr(),
                 _native.current_stream_ptr(x.device))
         _native.check(rc, "affine_act_forward")
         ctx.relu, ctx.has_res = bool(relu), res is not None
         ctx.save_for_backward(y if relu else None, scale)
-        ctx.shape = (C, H * W)
+        ctx.shape = (C, inner, fmt)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         y, scale = ctx.saved_tensors
-        dy = dy.contiguous()
-        C, inner = ctx.shape
-        dx = torch.empty_like(dy)
-        dres = torch.empty_like(dy) if ctx.has_res and ctx.needs_input_grad[3] else None
+        C, inner, fmt = ctx.shape
+        dy = dy.contiguous(memory_format=fmt)
+        dx = torch.empty_like(dy, memory_format=fmt)
+        dres = (torch.empty_like(dy, memory_format=fmt)
+                if ctx.has_res and ctx.needs_input_grad[3] else None)
         with torch.cuda.device(dy.device):
             rc = _native.lib.datr_affine_act_backward_f32(
                 dy.data_ptr(), 0 if y is None else y.data_ptr(), scale.data_ptr(), dy.numel(), C,

@@ -17,7 +17,8 @@ def reference(x, w, b, rm, rv, res, relu):
 @pytest.mark.parametrize("shape", [(2, 64, 50, 84), (1, 2048, 25, 42), (3, 7, 5, 3), (4, 256, 8, 8)])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("with_res", [True, False])
-def test_frozen_bn_act(shape, relu, with_res):
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_frozen_bn_act(shape, relu, with_res, nhwc):
     from datr_amd.backbone import FrozenBatchNorm2d
     from datr_amd.fused import frozen_bn_act
     dev = torch.device("cuda:0")
@@ -29,8 +30,10 @@ def test_frozen_bn_act(shape, relu, with_res):
     bn.running_mean.copy_(torch.randn(C, generator=g))
     bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
     bn.to(dev)
-    x = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
-    res = torch.randn(shape, generator=g).to(dev).requires_grad_(True) if with_res else None
+    fmt = torch.channels_last if nhwc else torch.contiguous_format
+    x = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=fmt).requires_grad_(True)
+    res = (torch.randn(shape, generator=g).to(dev).contiguous(memory_format=fmt).requires_grad_(True)
+           if with_res else None)
     go = torch.randn(shape, generator=g).to(dev)
     y = frozen_bn_act(x, *bn.scale_shift(), residual=res, relu=relu)
     y.backward(go)
