@@ -591,33 +591,49 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
                                  const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
                                  int64_t L, int64_t Lq, int64_t P, float *grad_value,
                                  float *grad_loc, float *grad_attn, void *stream) {
-    // The tiled kernel needs the level geometry on the host (grid size) and the
-    // pixels-are-the-queries layout; anything else takes the row kernel.
-    bool tiled = shapes_host && level_start_host && D == 32 && Lq == S && L >= 1 &&
-                 L <= DATR_TILED_MAX_LEVELS && P >= 1 && P <= 4 && N > 0 &&
-                 S * M * D * 4 < (int64_t)kOutOfRange;
+    // The tiled kernel needs the level geometry on the host (grid size, window maths); anything
+    // it does not cover takes the row kernel.
+    bool tiled = shapes_host && level_start_host && D == 32 && L >= 1 &&
+                 L <= DATR_TILED_MAX_LEVELS && P >= 1 && P <= 4 && N > 0 && Lq >= 64 &&
+                 S * M * D * 4 < (int64_t)kOutOfRange && Lq * M * L * P < (int64_t)1 << 30;
     DatrTiledMeta meta;
     if (tiled) {
         meta.L = (int)L;
+        meta.Lq = (int)Lq;
         int64_t expect = 0;
-        int base = 0;
         for (int l = 0; l < L; ++l) {
             const int64_t H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
             if (H <= 0 || W <= 0 || H > 32000 || W > 32000 || level_start_host[l] != expect) {
                 tiled = false;
                 break;
             }
-            meta.lv[l].H = (int)H;
-            meta.lv[l].W = (int)W;
-            meta.lv[l].start = (int)expect;
-            meta.lv[l].tiles_x = (int)((W + DATR_TILE_W - 1) / DATR_TILE_W);
-            meta.lv[l].tiles_y = (int)((H + DATR_TILE_H - 1) / DATR_TILE_H);
-            meta.lv[l].tile_base = base;
-            base += meta.lv[l].tiles_x * meta.lv[l].tiles_y;
+            meta.lv[l] = DatrTileLevel{(int)H, (int)W, (int)expect, 0, 0, 0};
             expect += H * W;
         }
-        meta.total_tiles = base;
         if (expect != S) tiled = false;
+    }
+    if (tiled) {
+        int base = 0;
+        if (Lq == S) {                       // pyramid mode: 16 x 8 pixel tiles per level
+            meta.QL = (int)L;
+            meta.tile_w = DATR_TILE_W;
+            meta.tile_h = DATR_TILE_H;
+            for (int l = 0; l < L; ++l) {
+                meta.qlv[l] = meta.lv[l];
+                meta.qlv[l].tiles_x = (meta.lv[l].W + DATR_TILE_W - 1) / DATR_TILE_W;
+                meta.qlv[l].tiles_y = (meta.lv[l].H + DATR_TILE_H - 1) / DATR_TILE_H;
+                meta.qlv[l].tile_base = base;
+                base += meta.qlv[l].tiles_x * meta.qlv[l].tiles_y;
+            }
+        } else {                             // linear mode: 128 consecutive queries per tile
+            meta.QL = 1;
+            meta.tile_w = DATR_TILE_LINEAR;
+            meta.tile_h = 1;
+            meta.qlv[0] = DatrTileLevel{1, (int)Lq, 0,
+                                        (int)((Lq + DATR_TILE_LINEAR - 1) / DATR_TILE_LINEAR), 1, 0};
+            base = meta.qlv[0].tiles_x;
+        }
+        meta.total_tiles = base;
     }
     if (!tiled)
         return datr_msda_backward_f32(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L,

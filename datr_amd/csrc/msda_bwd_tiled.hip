@@ -1,7 +1,10 @@
-// msda_bwd_tiled.hip -- MSDA backward for "self-attention over the pyramid" calls (Lq == S:
-// the queries ARE the pixels of the multi-level feature map, level-major raster order), the
-// encoder calls that make up 12 of the 24 backward launches of a DATR step and >97 % of the
-// backward's work (reference: /root/reference/models/dino/deformable_transformer.py:807-809
+// msda_bwd_tiled.hip -- query-tiled MSDA backward.  Built for "self-attention over the pyramid"
+// calls (Lq == S: the queries ARE the pixels of the multi-level feature map, level-major raster
+// order; workgroup tile = 16 x 8 pixels), the encoder calls that make up half of the backward
+// launches of a DATR step and >97 % of the backward's work; also used in LINEAR mode (tile =
+// 128 consecutive queries) for the decoder calls, where the queries have no spatial order but
+// the coarse levels (273 / 1050 rows) still fit the window and are exactly where hundreds of
+// de-noising copies of the same ground-truth box collide on the same rows (reference: /root/reference/models/dino/deformable_transformer.py:807-809
 // -> ms_deform_im2col_cuda.cuh:301-403).
 //
 // Why a second kernel.  grad_value is a scatter-add of 728 M floats per encoder call.  On
@@ -63,7 +66,6 @@ constexpr int kWaves = kThreads / 64;
 static_assert(kWaves <= 16, "fctl holds 16 per-wave partials per quantity");
 constexpr int kLPR = 8;                 // lanes per 32-channel row (float4 each)
 constexpr int kGroups = kThreads / kLPR;
-constexpr int kTW = DATR_TILE_W, kTH = DATR_TILE_H;
 constexpr int kWinRows = 480;           // rows (x 32 ch x 4 B = 60 KB) of the accumulation window
 constexpr int kMaxPairs = 512;          // kTQ * P with P <= 4
 constexpr unsigned kOutOfRange = 0x80000000u;
@@ -114,20 +116,20 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
     int *ctl = reinterpret_cast<int *>(touched + ((kWinRows + 15) & ~15));         // 16 ints
     float *fctl = reinterpret_cast<float *>(ctl + 16);                             // 32 floats
 
-    const int L = meta.L, K = L * P, Lq = S;
+    const int L = meta.L, K = L * P, Lq = meta.Lq;
     const int bid = blockIdx.x;
     const int m = bid % M;
     const int tile = (bid / M) % meta.total_tiles;
     const int n = bid / (M * meta.total_tiles);
     int lq = 0;
-    while (lq + 1 < L && tile >= meta.lv[lq + 1].tile_base) ++lq;
-    const int tl = tile - meta.lv[lq].tile_base;
-    const int tx = tl % meta.lv[lq].tiles_x, ty = tl / meta.lv[lq].tiles_x;
-    const int qx0 = tx * kTW, qy0 = ty * kTH;
-    const int qW = meta.lv[lq].W;
-    const int tw = min(kTW, qW - qx0), th = min(kTH, meta.lv[lq].H - qy0);
+    while (lq + 1 < meta.QL && tile >= meta.qlv[lq + 1].tile_base) ++lq;
+    const int tl = tile - meta.qlv[lq].tile_base;
+    const int tx = tl % meta.qlv[lq].tiles_x, ty = tl / meta.qlv[lq].tiles_x;
+    const int qx0 = tx * meta.tile_w, qy0 = ty * meta.tile_h;
+    const int qW = meta.qlv[lq].W;
+    const int tw = min(meta.tile_w, qW - qx0), th = min(meta.tile_h, meta.qlv[lq].H - qy0);
     const int nq = tw * th;
-    const int q_base = meta.lv[lq].start + qy0 * qW + qx0;
+    const int q_base = meta.qlv[lq].start + qy0 * qW + qx0;
 
     const int tid = threadIdx.x, g = tid / kLPR, j = tid % kLPR;
     const int wave = tid >> 6;

@@ -2,20 +2,28 @@
 #pragma once
 #include <cstdint>
 
-#define DATR_TILE_W 16
+#define DATR_TILE_W 16            // pyramid mode: 16 x 8 queries of one level per workgroup
 #define DATR_TILE_H 8
+#define DATR_TILE_LINEAR 128      // linear mode: 128 consecutive queries per workgroup
 #define DATR_TILED_MAX_LEVELS 8
 
 struct DatrTileLevel {
-    int H, W, start;        // level geometry (rows, cols, first token index)
-    int tiles_x, tiles_y;   // number of DATR_TILE_W x DATR_TILE_H query tiles covering it
+    int H, W, start;        // geometry (rows, cols, first index)
+    int tiles_x, tiles_y;   // number of tile_w x tile_h tiles covering it
     int tile_base;          // index of this level's first tile
 };
 
 struct DatrTiledMeta {
-    int L;
+    int L;                                   // target (value) levels
+    DatrTileLevel lv[DATR_TILED_MAX_LEVELS]; // target level geometry (tiles_* unused)
+    // how the Lq queries are cut into workgroup tiles: in pyramid mode (Lq == S) the queries ARE
+    // the target pixels, QL == L and qlv == lv geometry; in linear mode QL == 1 and qlv[0] is
+    // the 1 x Lq strip of queries
+    int QL;
+    DatrTileLevel qlv[DATR_TILED_MAX_LEVELS];
+    int tile_w, tile_h;
     int total_tiles;
-    DatrTileLevel lv[DATR_TILED_MAX_LEVELS];
+    int Lq;
 };
 
 extern "C" int datr_internal_msda_bwd_tiled_d32(

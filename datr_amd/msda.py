@@ -113,8 +113,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
         stream = _native.current_stream_ptr(value.device)
-        if sfx == "f32" and Lq == S and D == 32:
-            # encoder self-attention: the query-tiled kernel needs the geometry on the host
+        if sfx == "f32" and D == 32 and Lq >= 64:
+            # query-tiled backward (LDS accumulation): needs the geometry on the host
             sh_host, ls_host = _host_meta(shapes, lsi)
             rc = _native.lib.datr_msda_backward_tiled_f32(
                 grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),

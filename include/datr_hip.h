@@ -73,11 +73,11 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
 /* Same contract as datr_msda_backward_f32, for callers that also hold HOST copies of `shapes`
  * and `level_start` (the reference builds both from python ints,
  * /root/reference/models/dino/deformable_transformer.py:267-290, so a binding has them for
- * free).  When Lq == S -- the queries are the pyramid's own pixels, i.e. the encoder's
- * self-attention -- and D == 32, a query-tiled kernel accumulates grad_value in LDS (fixed
- * point) and flushes each touched row once, instead of one global float atomic per
- * contribution; every other shape falls through to datr_msda_backward_f32.  The host arrays
- * are only read during the call. */
+ * free).  For D == 32 a query-tiled kernel accumulates grad_value in LDS (fixed point) and
+ * flushes each touched row once, instead of one global float atomic per contribution: tiles
+ * are 16 x 8 pixels when Lq == S (the queries are the pyramid's own pixels -- the encoder's
+ * self-attention) and 128 consecutive queries otherwise (decoder); every other shape falls
+ * through to datr_msda_backward_f32.  The host arrays are only read during the call. */
 int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
                                  const int64_t *level_start, const int64_t *shapes_host,
                                  const int64_t *level_start_host, const float *loc,
