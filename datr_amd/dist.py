@@ -149,9 +149,14 @@ def init_distributed(backend: Optional[str] = None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" == RCCL on ROCm
+            # "nccl" == RCCL on ROCm.  DATR_DIST_BACKEND=gloo lets several ranks share one GPU
+            # (functional testing of the multi-process path on a 1-GPU box).
+            backend = os.environ.get("DATR_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        elif torch.cuda.is_available():
+            local_rank = local_rank % torch.cuda.device_count()
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
         dist.barrier()
     return rank, local_rank, world
