@@ -17,12 +17,28 @@ import torch
 from .nested import reduce_dict
 
 
+def _backward_and_step(model, optimizer, losses, max_norm, scaler, amp):
+    optimizer.zero_grad()
+    if amp:
+        scaler.scale(losses).backward()
+        if max_norm > 0:
+            scaler.unscale_(optimizer)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        losses.backward()
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        optimizer.step()
+
+
 def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loader: Iterable,
                     optimizer: torch.optim.Optimizer, device: torch.device, epoch: int,
                     max_norm: float = 0, wo_class_error=False, lr_scheduler=None, args=None,
                     logger=None, ema_m=None):
     amp = bool(getattr(args, "amp", False))
-    scaler = torch.cuda.amp.GradScaler(enabled=amp)
+    scaler = torch.amp.GradScaler("cuda", enabled=amp)
     need_tgt_for_training = bool(getattr(args, "use_dn", False))
     model.train()
     criterion.train()
@@ -73,6 +89,97 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             sums[k] += v
             counts[k] += 1
         last = stats
+        steps += 1
+        if getattr(args, "debug", False) and steps % 15 == 0:
+            print("BREAK!" * 5)
+            break
+    resstat = {k: sums[k] / counts[k] for k in sums if counts[k] > 0}
+    resstat["_last"] = last
+    return resstat
+
+
+def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loader,
+                                       data_loader_strong_aug, optimizer, device, epoch,
+                                       max_norm: float = 0, wo_class_error=False, lr_scheduler=None,
+                                       args=None, logger=None, ema_m=None):
+    """Teacher-student epoch: counterpart of the reference's
+    `engine.train_one_epoch_with_self_training` (/root/reference/engine.py:146-342).  Per step:
+    the EMA teacher (eval mode) predicts the weakly-augmented target images -> PostProcess with
+    num_select=100 on unit sizes -> per-class threshold -> class-aware NMS(0.7)[:100] ->
+    pseudo targets; the student sees source + strongly-augmented target images with
+    self_training_flag=True; loss = source losses + loss_self_training * target losses."""
+    import numpy as np
+
+    from .detector import PostProcess
+    from .self_training import (deal_pesudo_label, get_pseudo_label_via_threshold,
+                                get_unlabel_img, get_valid_output, rescale_pseudo_targets,
+                                spilt_output)
+    amp = bool(getattr(args, "amp", False))
+    scaler = torch.amp.GradScaler("cuda", enabled=amp)
+    need_tgt_for_training = bool(getattr(args, "use_dn", False))
+    model.train()
+    criterion.train()
+    post = PostProcess()                      # default-constructed: num_select = 100 (engine.py:159)
+    loader = data_loader_strong_aug if data_loader_strong_aug is not None else data_loader
+    sums, counts = defaultdict(float), defaultdict(int)
+    last, steps = {}, 0
+    for samples, source_labels, target_labels, samples_strong_aug in loader:
+        samples = samples.to(device)
+        source_labels = [{k: v.to(device) for k, v in t.items()} for t in source_labels]
+        if samples_strong_aug is not None:
+            samples_strong_aug = samples_strong_aug.to(device)
+        unlabel_img = get_unlabel_img(samples)
+        with torch.no_grad():
+            teacher_out = teacher_model.ema(unlabel_img)
+        target_labels = [{k: v.to(device) for k, v in t.items()} for t in target_labels]
+        unit = torch.ones(len(target_labels), 2, dtype=torch.long, device=device)
+        results = post(teacher_out, unit, not_to_xyxy=True)
+        threshold = np.asarray([args.pseudo_label_threshold] * args.num_classes)
+        idx_list, labels_d, boxes_d, scores_d = get_pseudo_label_via_threshold(results, threshold=threshold)
+        pseudo = deal_pesudo_label(target_labels, idx_list, labels_d, boxes_d, scores_d)
+        pseudo = rescale_pseudo_targets(unlabel_img, pseudo)
+
+        with torch.autocast(device_type=device.type, enabled=amp):
+            if need_tgt_for_training:
+                outputs = model(samples_strong_aug, source_labels, self_training_flag=True)
+            else:
+                outputs = model(samples_strong_aug, self_training_flag=True)
+            source_outputs, target_outputs = spilt_output(outputs)
+            valid_target_outputs, pseudo_list = get_valid_output(target_outputs, pseudo, idx_list)
+            weight_dict = criterion.weight_dict
+            loss_dict_source = criterion(source_outputs, source_labels, target_domain_flag=False)
+            loss_dict_target = criterion(valid_target_outputs, pseudo_list, target_domain_flag=True)
+            losses_source = sum(loss_dict_source[k] * weight_dict[k] for k in loss_dict_source if k in weight_dict)
+            losses_target = sum(loss_dict_target[k] * weight_dict[k] for k in loss_dict_target if k in weight_dict)
+            if isinstance(losses_target, int) and losses_target == 0:
+                losses_target = torch.tensor(0)
+            losses = losses_source + losses_target * weight_dict["loss_self_training"]
+
+        loss_dict_reduced = reduce_dict(loss_dict_source)
+        scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
+        loss_value = sum(scaled.values()).item()
+        if not math.isfinite(loss_value):
+            print(f"Loss is {loss_value}, stopping training")
+            print(loss_dict_reduced)
+            sys.exit(1)
+        _backward_and_step(model, optimizer, losses, max_norm, scaler, amp)
+        if getattr(args, "onecyclelr", False):
+            lr_scheduler.step()
+        if getattr(args, "use_ema", False) and epoch >= getattr(args, "ema_epoch", 0):
+            ema_m.update(model)
+        stats = {"loss": loss_value, "lr": optimizer.param_groups[0]["lr"],
+                 "loss_self_training_sum": float(losses_target.detach()),
+                 "num_pseudo_images": float(len(idx_list))}
+        stats.update({k: float(v) for k, v in scaled.items()})
+        stats.update({f"{k}_unscaled": float(v) for k, v in loss_dict_reduced.items()})
+        if "class_error" in loss_dict_reduced:
+            stats["class_error"] = float(loss_dict_reduced["class_error"])
+        for k, v in stats.items():
+            sums[k] += v
+            counts[k] += 1
+        last = dict(stats, total_loss=float(losses.detach()),
+                    target_loss_dict={k: float(v.detach()) for k, v in loss_dict_target.items()},
+                    pseudo_targets=pseudo_list)
         steps += 1
         if getattr(args, "debug", False) and steps % 15 == 0:
             print("BREAK!" * 5)

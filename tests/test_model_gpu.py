@@ -103,3 +103,32 @@ def test_two_gpu_runs_agree():
     for a, b in zip(outs[0][2], outs[1][2]):
         for (s1, t1), (s2, t2) in zip(a, b):
             assert torch.equal(s1, s2) and torch.equal(t1, t2)
+
+
+def test_teacher_student_step_runs_on_gpu():
+    """Config-5 smoke on the HIP path: EMA teacher -> pseudo labels -> student step."""
+    import argparse
+    import synth
+    from datr_amd.config import get_param_dict
+    from datr_amd.ema import ModelEMA
+    from datr_amd.engine import train_one_epoch_with_self_training
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    dev = torch.device("cuda:0")
+    g = load_npz("selftrain_step.npz")
+    args, model, criterion, _ = build_model("cuda:0")
+    args.pseudo_label_threshold = float(g["threshold"])
+    teacher = ModelEMA(model, decay=args.ema_decay_teacher)
+    opt = torch.optim.AdamW(get_param_dict(args, model), lr=args.lr, weight_decay=args.weight_decay)
+    imgs, targets = synth.synth_batch()
+    meta = [{"size": torch.tensor([240, 300]), "orig_size": torch.tensor([480, 600]),
+             "image_id": torch.tensor([7]), "area": torch.tensor([1.0]), "iscrowd": torch.tensor([0])}]
+    loader = [(nested_tensor_from_tensor_list(imgs), tuple(targets), tuple(meta),
+               nested_tensor_from_tensor_list(imgs))]
+    stats = train_one_epoch_with_self_training(model, teacher, criterion, loader, loader, opt, dev, 0,
+                                               args.clip_max_norm, args=args)
+    last = stats["_last"]
+    assert last["num_pseudo_images"] == 1 and np.isfinite(stats["loss"])
+    # the teacher sees the same weights and the same weak image as in the golden run
+    n_ref = len(g["pseudo_labels"])
+    assert abs(len(last["pseudo_targets"][0]["labels"]) - n_ref) <= max(2, n_ref // 5)
+    assert abs(stats["loss"] - float(g["stat_values"][list(g["stat_keys"]).index("loss")])) < 0.05 * stats["loss"]
