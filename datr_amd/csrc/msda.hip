@@ -585,6 +585,62 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
     }
 }
 
+// Level geometry + query tiling for the tiled kernels; false when the shape is not covered.
+static bool build_tiled_meta(DatrTiledMeta &meta, const int64_t *shapes_host,
+                             const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
+                             int64_t D, int64_t L, int64_t Lq, int64_t P, bool allow_linear) {
+    if (!(shapes_host && level_start_host && D == 32 && L >= 1 && L <= DATR_TILED_MAX_LEVELS &&
+          P >= 1 && P <= 4 && N > 0 && Lq >= 64 && S * M * D * 4 < (int64_t)kOutOfRange &&
+          Lq * M * L * P < ((int64_t)1 << 30)))
+        return false;
+    meta.L = (int)L;
+    meta.Lq = (int)Lq;
+    int64_t expect = 0;
+    for (int l = 0; l < L; ++l) {
+        const int64_t H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+        if (H <= 0 || W <= 0 || H > 32000 || W > 32000 || level_start_host[l] != expect) return false;
+        meta.lv[l] = DatrTileLevel{(int)H, (int)W, (int)expect, 0, 0, 0};
+        expect += H * W;
+    }
+    if (expect != S) return false;
+    int base = 0;
+    if (Lq == S) {                       // pyramid mode: 16 x 8 pixel tiles per level
+        meta.QL = (int)L;
+        meta.tile_w = DATR_TILE_W;
+        meta.tile_h = DATR_TILE_H;
+        for (int l = 0; l < L; ++l) {
+            meta.qlv[l] = meta.lv[l];
+            meta.qlv[l].tiles_x = (meta.lv[l].W + DATR_TILE_W - 1) / DATR_TILE_W;
+            meta.qlv[l].tiles_y = (meta.lv[l].H + DATR_TILE_H - 1) / DATR_TILE_H;
+            meta.qlv[l].tile_base = base;
+            base += meta.qlv[l].tiles_x * meta.qlv[l].tiles_y;
+        }
+    } else {                             // linear mode: 128 consecutive queries per tile
+        if (!allow_linear) return false;
+        meta.QL = 1;
+        meta.tile_w = DATR_TILE_LINEAR;
+        meta.tile_h = 1;
+        meta.qlv[0] = DatrTileLevel{1, (int)Lq, 0,
+                                    (int)((Lq + DATR_TILE_LINEAR - 1) / DATR_TILE_LINEAR), 1, 0};
+        base = meta.qlv[0].tiles_x;
+    }
+    meta.total_tiles = base;
+    return true;
+}
+
+int datr_msda_forward_tiled_f32(const float *value, const int64_t *shapes,
+                                const int64_t *level_start, const int64_t *shapes_host,
+                                const int64_t *level_start_host, const float *loc,
+                                const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                int64_t L, int64_t Lq, int64_t P, float *out, void *stream) {
+    DatrTiledMeta meta;
+    if (!build_tiled_meta(meta, shapes_host, level_start_host, N, S, M, D, L, Lq, P, false))
+        return datr_msda_forward_f32(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
+                                     out, stream);
+    if (!value || !loc || !attn || !out) return DATR_EINVAL;
+    return datr_internal_msda_fwd_tiled_d32(value, loc, attn, &meta, N, S, M, P, out, stream);
+}
+
 int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
                                  const int64_t *level_start, const int64_t *shapes_host,
                                  const int64_t *level_start_host, const float *loc,
@@ -593,49 +649,8 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
                                  float *grad_loc, float *grad_attn, void *stream) {
     // The tiled kernel needs the level geometry on the host (grid size, window maths); anything
     // it does not cover takes the row kernel.
-    bool tiled = shapes_host && level_start_host && D == 32 && L >= 1 &&
-                 L <= DATR_TILED_MAX_LEVELS && P >= 1 && P <= 4 && N > 0 && Lq >= 64 &&
-                 S * M * D * 4 < (int64_t)kOutOfRange && Lq * M * L * P < (int64_t)1 << 30;
     DatrTiledMeta meta;
-    if (tiled) {
-        meta.L = (int)L;
-        meta.Lq = (int)Lq;
-        int64_t expect = 0;
-        for (int l = 0; l < L; ++l) {
-            const int64_t H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
-            if (H <= 0 || W <= 0 || H > 32000 || W > 32000 || level_start_host[l] != expect) {
-                tiled = false;
-                break;
-            }
-            meta.lv[l] = DatrTileLevel{(int)H, (int)W, (int)expect, 0, 0, 0};
-            expect += H * W;
-        }
-        if (expect != S) tiled = false;
-    }
-    if (tiled) {
-        int base = 0;
-        if (Lq == S) {                       // pyramid mode: 16 x 8 pixel tiles per level
-            meta.QL = (int)L;
-            meta.tile_w = DATR_TILE_W;
-            meta.tile_h = DATR_TILE_H;
-            for (int l = 0; l < L; ++l) {
-                meta.qlv[l] = meta.lv[l];
-                meta.qlv[l].tiles_x = (meta.lv[l].W + DATR_TILE_W - 1) / DATR_TILE_W;
-                meta.qlv[l].tiles_y = (meta.lv[l].H + DATR_TILE_H - 1) / DATR_TILE_H;
-                meta.qlv[l].tile_base = base;
-                base += meta.qlv[l].tiles_x * meta.qlv[l].tiles_y;
-            }
-        } else {                             // linear mode: 128 consecutive queries per tile
-            meta.QL = 1;
-            meta.tile_w = DATR_TILE_LINEAR;
-            meta.tile_h = 1;
-            meta.qlv[0] = DatrTileLevel{1, (int)Lq, 0,
-                                        (int)((Lq + DATR_TILE_LINEAR - 1) / DATR_TILE_LINEAR), 1, 0};
-            base = meta.qlv[0].tiles_x;
-        }
-        meta.total_tiles = base;
-    }
-    if (!tiled)
+    if (!build_tiled_meta(meta, shapes_host, level_start_host, N, S, M, D, L, Lq, P, true))
         return datr_msda_backward_f32(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L,
                                       Lq, P, grad_value, grad_loc, grad_attn, stream);
     if (!grad_out || !value || !loc || !attn || !grad_value || !grad_loc || !grad_attn)

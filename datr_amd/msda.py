@@ -59,6 +59,11 @@ def _as_int64(t: torch.Tensor) -> torch.Tensor:
 
 
 _HOST_META = {}
+# The query-tiled forward (csrc/msda_fwd_tiled.hip) is correct and tested but, as measured in
+# round 1, SLOWER than the row kernel on the encoder call (158 us vs 105 us: four
+# stage -> barrier -> gather -> barrier rounds at 16 waves per CU are latency-bound), so the row
+# kernel stays the default.  DATR_MSDA_TILED_FWD=1 switches it on for A/B measurements.
+TILED_FORWARD = __import__("os").environ.get("DATR_MSDA_TILED_FWD", "0") == "1"
 
 
 def _host_meta(shapes: torch.Tensor, lsi: torch.Tensor):
@@ -90,10 +95,18 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     shapes, lsi = _as_int64(spatial_shapes), _as_int64(level_start_index)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
-        fn = getattr(_native.lib, f"datr_msda_forward_{sfx}")
-        rc = fn(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), sampling_loc.data_ptr(),
-                attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(),
-                _native.current_stream_ptr(value.device))
+        stream = _native.current_stream_ptr(value.device)
+        if sfx == "f32" and D == 32 and Lq == S and TILED_FORWARD:
+            # encoder self-attention: query-tiled forward, value windows staged in LDS
+            sh_host, ls_host = _host_meta(shapes, lsi)
+            rc = _native.lib.datr_msda_forward_tiled_f32(
+                value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), sh_host.ctypes.data,
+                ls_host.ctypes.data, sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                N, S, M, D, L, Lq, P, out.data_ptr(), stream)
+        else:
+            fn = getattr(_native.lib, f"datr_msda_forward_{sfx}")
+            rc = fn(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), sampling_loc.data_ptr(),
+                    attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), stream)
     _native.check(rc, "ms_deform_attn_forward")
     return out
 

@@ -70,14 +70,21 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
                            int64_t L, int64_t Lq, int64_t P,
                            float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
-/* Same contract as datr_msda_backward_f32, for callers that also hold HOST copies of `shapes`
+/* Same contracts as datr_msda_forward_f32 / datr_msda_backward_f32, for callers that also hold HOST copies of `shapes`
  * and `level_start` (the reference builds both from python ints,
  * /root/reference/models/dino/deformable_transformer.py:267-290, so a binding has them for
- * free).  For D == 32 a query-tiled kernel accumulates grad_value in LDS (fixed point) and
- * flushes each touched row once, instead of one global float atomic per contribution: tiles
- * are 16 x 8 pixels when Lq == S (the queries are the pyramid's own pixels -- the encoder's
- * self-attention) and 128 consecutive queries otherwise (decoder); every other shape falls
- * through to datr_msda_backward_f32.  The host arrays are only read during the call. */
+ * free).  For D == 32 the query-tiled kernels work on 16 x 8 pixel tiles when Lq == S (the
+ * queries are the pyramid's own pixels -- the encoder's self-attention): the forward stages a
+ * window of value rows per level in LDS and gathers from there; the backward accumulates
+ * grad_value in LDS (fixed point) and flushes each touched row once instead of one global
+ * float atomic per contribution (also for other Lq, with tiles of 128 consecutive queries).
+ * Every other shape falls through to the plain entry points.  The host arrays are only read
+ * during the call. */
+int datr_msda_forward_tiled_f32(const float *value, const int64_t *shapes,
+                                const int64_t *level_start, const int64_t *shapes_host,
+                                const int64_t *level_start_host, const float *loc,
+                                const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                int64_t L, int64_t Lq, int64_t P, float *out, void *stream);
 int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
                                  const int64_t *level_start, const int64_t *shapes_host,
                                  const int64_t *level_start_host, const float *loc,

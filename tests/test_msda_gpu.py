@@ -165,6 +165,28 @@ def test_tiled_backward_for_pyramid_queries(M, O, dev, shapes, spread):
     assert torch.count_nonzero(gv0) == 0 and torch.count_nonzero(gl0) == 0 and torch.count_nonzero(ga0) == 0
 
 
+@pytest.mark.parametrize("shapes,spread", [
+    ([(20, 27), (10, 14), (5, 7), (3, 4)], 1.5),
+    ([(20, 27), (10, 14), (5, 7), (3, 4)], 12.0),      # mostly out-of-window -> global fetches
+    ([(33, 50), (17, 25)], 3.0),
+])
+def test_tiled_forward_matches_oracle(M, O, dev, shapes, spread, monkeypatch):
+    """The experimental query-tiled forward (off by default, see datr_amd/msda.py) stays
+    parity-green: LDS-staged windows + out-of-window global fetches == oracle."""
+    monkeypatch.setattr(M, "TILED_FORWARD", True)
+    N, Mh, D, P = 2, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, shapes, P, seed=13)
+    S = value.shape[1]
+    loc = pyramid_locs(shapes, N, Mh, P, spread, seed=7)
+    g = torch.Generator().manual_seed(8)
+    attn = torch.softmax(torch.randn(N, S, Mh, len(shapes) * P, generator=g), -1).view(N, S, Mh, len(shapes), P)
+    out = run_hip(M, dev, value, sh, lsi, loc, attn)
+    torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
+    monkeypatch.setattr(M, "TILED_FORWARD", False)
+    rows = run_hip(M, dev, value, sh, lsi, loc, attn)
+    torch.testing.assert_close(out, rows, rtol=1e-5, atol=1e-7)
+
+
 def test_empty_and_fully_out_of_range(M, O, dev):
     value, sh, lsi, loc, attn = O.random_inputs(1, 0, 8, 32, [(4, 4)], 4, seed=1)
     assert run_hip(M, dev, value, sh, lsi, loc, attn).shape == (1, 0, 256)
