@@ -62,3 +62,25 @@ def frozen_bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
     if residual is not None:
         y = y + residual
     return torch.relu(y) if relu else y
+
+
+def conv3x3_lrelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None,
+                  slope: float = 1.0, out_scale: float = 1.0) -> torch.Tensor:
+    """out_scale * leaky_relu(conv2d(x, weight, bias, stride 1, padding 1), slope) as ONE
+    exact-fp32 MFMA implicit-GEMM kernel (csrc/conv3x3.hip) -- the layer shape of
+    `FCDiscriminator_img` (/root/reference/models/dino/DA_utils.py:61-79).  Forward only
+    (no autograd); measured against MIOpen in tools/bench_conv3x3.py."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    assert weight.shape == (Cout, Cin, 3, 3)
+    wt = weight.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).contiguous()
+    x = x.contiguous()
+    y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = _native.lib.datr_conv3x3_forward_f32(
+            x.data_ptr(), wt.data_ptr(), 0 if bias is None else bias.contiguous().data_ptr(),
+            N, Cin, Cout, H, W, float(slope), float(out_scale), y.data_ptr(),
+            _native.current_stream_ptr(x.device))
+    _native.check(rc, "conv3x3_forward")
+    return y

@@ -153,6 +153,20 @@ int datr_affine_act_backward_f32(const float *dy, const float *y, const float *s
                                  int64_t C, int64_t inner, int relu, float *dx, float *dres,
                                  void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution, NCHW fp32, exact-fp32 MFMA implicit GEMM, with fused
+ * bias + LeakyReLU epilogue -- the layers of the image-level domain discriminator
+ * (`FCDiscriminator_img`, /root/reference/models/dino/DA_utils.py:61-79).
+ *   x  [N, Cin, H, W]     wt [9*Cin, Cout]  = W.permute(2,3,1,0).reshape(9*Cin, Cout)
+ *   y  [N, Cout, H, W]  = out_scale * lrelu_slope( bias + conv3x3(x, W) )
+ * `bias` may be NULL; slope 1 = no activation.  Cin must be a multiple of 16.
+ * The data gradient is the same call on dY with the transformed weights
+ * W'[ci,co,r,s] = W[co,ci,2-r,2-s]; out_scale = -1 folds a gradient-reversal layer in.
+ * ------------------------------------------------------------------------------------------ */
+int datr_conv3x3_forward_f32(const float *x, const float *wt, const float *bias,
+                             int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                             float slope, float out_scale, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

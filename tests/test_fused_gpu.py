@@ -58,3 +58,26 @@ def test_scale_shift_cache_invalidates_on_load():
                         "running_mean": torch.zeros(4), "running_var": torch.ones(4)})
     s2, _ = bn.scale_shift()
     torch.testing.assert_close(s2, torch.full((4,), 2.0, device="cuda") / (1 + 1e-5) ** 0.5)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 13, 21, 48), (1, 256, 25, 42, 128), (3, 16, 7, 5, 1),
+                                   (2, 128, 50, 84, 128)])
+@pytest.mark.parametrize("slope", [0.2, 1.0])
+def test_conv3x3_lrelu(shape, slope):
+    """MFMA implicit-GEMM conv3x3 (+bias +LeakyReLU) vs conv2d + leaky_relu in fp32
+    (/root/reference/models/dino/DA_utils.py:69-79).  Tolerance 1e-4·max|y|: both sides are
+    fp32 sums of 9·Cin products in different orders."""
+    import torch.nn.functional as F
+    from datr_amd.fused import conv3x3_lrelu
+    N, Cin, H, W, Cout = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), slope)
+    out = conv3x3_lrelu(x, w, b, slope=slope)
+    assert (out.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    neg = conv3x3_lrelu(x, w, None, slope=slope, out_scale=-1.0)
+    ref2 = -F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=1), slope)
+    assert (neg.double() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
