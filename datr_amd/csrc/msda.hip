@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "datr_hip.h"
 #include "msda_tiled.h"
@@ -634,11 +635,12 @@ int datr_msda_forward_tiled_f32(const float *value, const int64_t *shapes,
                                 const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
                                 int64_t L, int64_t Lq, int64_t P, float *out, void *stream) {
     DatrTiledMeta meta;
-    if (!build_tiled_meta(meta, shapes_host, level_start_host, N, S, M, D, L, Lq, P, false))
+    if (P != 4 || L > 4 ||
+        !build_tiled_meta(meta, shapes_host, level_start_host, N, S, M, D, L, Lq, P, false))
         return datr_msda_forward_f32(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
                                      out, stream);
     if (!value || !loc || !attn || !out) return DATR_EINVAL;
-    return datr_internal_msda_fwd_tiled_d32(value, loc, attn, &meta, N, S, M, P, out, stream);
+    return datr_internal_msda_fwd_win_d32(value, loc, attn, &meta, N, S, M, P, out, stream);
 }
 
 int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,

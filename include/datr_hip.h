@@ -74,12 +74,13 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
  * and `level_start` (the reference builds both from python ints,
  * /root/reference/models/dino/deformable_transformer.py:267-290, so a binding has them for
  * free).  For D == 32 the query-tiled kernels work on 16 x 8 pixel tiles when Lq == S (the
- * queries are the pyramid's own pixels -- the encoder's self-attention): the forward stages a
- * window of value rows per level in LDS and gathers from there; the backward accumulates
- * grad_value in LDS (fixed point) and flushes each touched row once instead of one global
- * float atomic per contribution (also for other Lq, with tiles of 128 consecutive queries).
- * Every other shape falls through to the plain entry points.  The host arrays are only read
- * during the call. */
+ * queries are the pyramid's own pixels -- the encoder's self-attention).  The backward
+ * accumulates grad_value in LDS (fixed point) and flushes each touched row once instead of one
+ * global float atomic per contribution (also for other Lq, with tiles of 128 consecutive
+ * queries): this is the product path.  The forward (P == 4, L <= 4) stages a window of value rows
+ * per level in LDS and gathers from there; it is parity-green but measured slower than
+ * datr_msda_forward_f32 on MI355X and is kept for A/B measurements only.  Every other shape
+ * falls through to the plain entry points.  The host arrays are only read during the call. */
 int datr_msda_forward_tiled_f32(const float *value, const int64_t *shapes,
                                 const int64_t *level_start, const int64_t *shapes_host,
                                 const int64_t *level_start_host, const float *loc,
