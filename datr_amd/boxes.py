@@ -34,10 +34,18 @@ def box_iou(boxes1: Tensor, boxes2: Tensor):
     return inter / (union + 1e-6), union
 
 
-def generalized_box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
-    """Pairwise GIoU [N,M] of xyxy boxes."""
-    assert (boxes1[:, 2:] >= boxes1[:, :2]).all()
-    assert (boxes2[:, 2:] >= boxes2[:, :2]).all()
+def boxes_are_valid(boxes: Tensor) -> Tensor:
+    """0-d bool tensor: every xyxy box has x2 >= x1 and y2 >= y1 (the condition box_ops.py:52-53
+    asserts), left on the boxes' device."""
+    return (boxes[:, 2:] >= boxes[:, :2]).all()
+
+
+def generalized_box_iou(boxes1: Tensor, boxes2: Tensor, check: bool = True) -> Tensor:
+    """Pairwise GIoU [N,M] of xyxy boxes.  `check=False` skips the reference's asserts (each one
+    a device->host sync); callers that do so test `boxes_are_valid` on the device instead."""
+    if check:
+        assert boxes_are_valid(boxes1)
+        assert boxes_are_valid(boxes2)
     iou, union = box_iou(boxes1, boxes2)
     lt = torch.min(boxes1[:, None, :2], boxes2[:, :2])
     rb = torch.max(boxes1[:, None, 2:], boxes2[:, 2:])

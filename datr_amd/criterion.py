@@ -41,6 +41,39 @@ def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: f
     return loss.mean(1).sum() / num_boxes
 
 
+_STATIC = {}
+
+
+def _cached(key, make):
+    t = _STATIC.get(key)
+    if t is None:
+        if len(_STATIC) > 512:
+            _STATIC.clear()
+        t = _STATIC[key] = make()
+    return t
+
+
+def _device_lengths(counts, device):
+    """float tensor of the per-image box counts, uploaded once per distinct count tuple (a
+    per-step upload from a python list is a synchronising copy)."""
+    return _cached(("len", counts, str(device)),
+                   lambda: torch.tensor(counts, dtype=torch.float32).to(device))
+
+
+def _static_index_columns(G, counts, device):
+    """(set index, image index, box offset) of every matched pair in (set, image, rank) order."""
+    def make():
+        b = torch.tensor([i for i, n in enumerate(counts) for _ in range(n)], dtype=torch.int64)
+        off, acc = [], 0
+        for n in counts:
+            off += [acc] * n
+            acc += n
+        off = torch.tensor(off, dtype=torch.int64)
+        g = torch.arange(G, dtype=torch.int64).repeat_interleave(len(b))
+        return g.to(device), b.repeat(G).to(device), off.repeat(G).to(device)
+    return _cached(("cols", G, counts, str(device)), make)
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses):
         super().__init__()
@@ -179,22 +212,31 @@ class SetCriterion(nn.Module):
             offsets.append(offsets[-1] + c)
         labels_cat = torch.cat([t["labels"] for t in targets])
         boxes_cat = torch.cat([t["boxes"] for t in targets])
-        gi, bi, qi, ti = [], [], [], []
-        for g, indices in enumerate(indices_per_out):
-            for b, (src, tgt) in enumerate(indices):
-                n = src.numel()
-                if n == 0:
-                    continue
-                gi.append(torch.full((n,), g, dtype=torch.int64, device=src.device))
-                bi.append(torch.full((n,), b, dtype=torch.int64, device=src.device))
-                qi.append(src)
-                ti.append(tgt + offsets[b])
-        if gi:
-            packed = torch.stack([torch.cat(gi), torch.cat(bi), torch.cat(qi), torch.cat(ti)])
-            packed = packed.to(device, non_blocking=True)
-            g_idx, b_idx, q_idx, t_idx = packed[0], packed[1], packed[2], packed[3]
+        packed = getattr(indices_per_out, "packed", None)
+        if packed is not None:
+            # indices straight from the device solver, already in (set, image, query) order: the
+            # set / image / box-offset columns are static per (G, counts) and cached
+            g_idx, b_idx, off_idx = _static_index_columns(G, tuple(counts), device)
+            q_idx = packed[0].reshape(-1)
+            t_idx = packed[1].reshape(-1) + off_idx
         else:
-            g_idx = b_idx = q_idx = t_idx = torch.zeros(0, dtype=torch.int64, device=device)
+            gi, bi, qi, ti = [], [], [], []
+            for g, indices in enumerate(indices_per_out):
+                for b, (src, tgt) in enumerate(indices):
+                    n = src.numel()
+                    if n == 0:
+                        continue
+                    gi.append(torch.full((n,), g, dtype=torch.int64, device=src.device))
+                    bi.append(torch.full((n,), b, dtype=torch.int64, device=src.device))
+                    qi.append(src)
+                    ti.append(tgt + offsets[b])
+            if gi:
+                packed = torch.stack([torch.cat(gi), torch.cat(bi), torch.cat(qi), torch.cat(ti)])
+                packed = packed.to(device, non_blocking=True)
+                g_idx, b_idx, q_idx, t_idx = packed[0], packed[1], packed[2], packed[3]
+            else:
+                g_idx = b_idx = q_idx = t_idx = torch.zeros(0, dtype=torch.int64, device=device)
+        n_first = offsets[-1] if len(indices_per_out) else 0     # pairs of set 0 come first
 
         res = [dict() for _ in range(G)]
         zeros_g = lambda: torch.zeros(G, dtype=logits.dtype, device=device)
@@ -209,9 +251,8 @@ class SetCriterion(nn.Module):
                 for g in range(G):
                     res[g]["loss_ce"] = loss_ce[g]
                 if log_first:
-                    first = g_idx == 0
                     res[0]["class_error"] = 100 - accuracy(
-                        logits[0][b_idx[first], q_idx[first]], matched_cls[first])[0]
+                        logits[0][b_idx[:n_first], q_idx[:n_first]], matched_cls[:n_first])[0]
             elif loss == "boxes":
                 src = boxes[g_idx, b_idx, q_idx]
                 tgt = boxes_cat[t_idx]
@@ -229,7 +270,7 @@ class SetCriterion(nn.Module):
                     res[g]["loss_xy"], res[g]["loss_hw"] = loss_xy[g], loss_hw[g]
             elif loss == "cardinality":
                 with torch.no_grad():
-                    lengths = torch.as_tensor(counts, device=device).float()
+                    lengths = _device_lengths(tuple(counts), device)
                     card_pred = (logits.argmax(-1) != C - 1).sum(-1).float()         # [G, B]
                     card_err = (card_pred - lengths[None]).abs().mean(-1)
                 for g in range(G):
@@ -320,6 +361,12 @@ class SetCriterion(nn.Module):
             losses.update({k + "_interm": v for k, v in interm_l.items() if k != "class_error"})
         for i, l_dict in enumerate(enc_l):
             losses.update({k + f"_enc_{i}": v for k, v in l_dict.items() if k != "class_error"})
+
+        poison = getattr(self.matcher, "poison", None)
+        if poison is not None and "loss_ce" in losses:
+            # NaN if the device matcher rejected a cost matrix (NaN costs / degenerate boxes: the
+            # reference raises there), else + 0.0 -- fails loudly without a host sync
+            losses["loss_ce"] = losses["loss_ce"] + poison
 
         if "da_output" in outputs:
             da = outputs["da_output"]

@@ -52,11 +52,17 @@ def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, lab
     noised_boxes = known_bboxs.clone()
 
     if label_noise_ratio > 0:
-        p = noise["label_p"].to(device) if noise is not None else torch.rand_like(noised_labels.float())
-        chosen = torch.nonzero(p < (label_noise_ratio * 0.5)).view(-1)
-        new_label = (noise["new_label"].to(device) if noise is not None
-                     else torch.randint_like(chosen, 0, num_classes))
-        noised_labels.scatter_(0, chosen, new_label)
+        if noise is not None:       # replayed draws (parity tests): the reference's exact sequence
+            p = noise["label_p"].to(device)
+            chosen = torch.nonzero(p < (label_noise_ratio * 0.5)).view(-1)
+            noised_labels.scatter_(0, chosen, noise["new_label"].to(device))
+        else:
+            # same distribution as dn_components.py:60-63 (flip each label with probability
+            # ratio/2 to a uniform class) without `nonzero`, whose data-dependent size costs a
+            # device->host sync; the random stream is not the reference's either way
+            p = torch.rand_like(noised_labels.float())
+            new_label = torch.randint_like(noised_labels, 0, num_classes)
+            noised_labels = torch.where(p < (label_noise_ratio * 0.5), new_label, noised_labels)
 
     single_pad = max_gt
     pad_size = int(single_pad * 2 * groups)

@@ -84,3 +84,58 @@ def conv3x3_lrelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = No
             _native.current_stream_ptr(x.device))
     _native.check(rc, "conv3x3_forward")
     return y
+
+
+class _FFNRelu(Function):
+    """y = linear2(relu(linear1(x))) with hand-placed fusion points:
+
+    forward   h = relu(x W1^T + b1) as ONE hipBLASLt GEMM with a bias+ReLU epilogue
+              (`torch._addmm_activation`; bit-identical to linear followed by relu, and no
+              separate clamp pass over the rows x d_ffn activation);  y = h W2^T + b2.
+    backward  dh = dy W2;  dz = dh * (h > 0) in place together with db1 = sum_rows(dz) in one HBM
+              pass (csrc/ffn.hip);  dx = dz W1,  dW1 = dz^T x,  dW2 = dy^T h,  db2 = sum_rows(dy).
+    Same saved activations as autograd's own graph (x and h)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        h = torch._addmm_activation(b1, x2, w1.t(), use_gelu=False)
+        y = torch.addmm(b2, h, w2.t())
+        ctx.save_for_backward(x2, h, w1, w2)
+        ctx.shape = shape
+        return y.view(*shape[:-1], w2.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, h, w1, w2 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        need = ctx.needs_input_grad
+        dw2 = dy2.t().mm(h) if need[3] else None
+        db2 = dy2.sum(0) if need[4] else None
+        dh = dy2.mm(w2)                                   # rows x d_ffn, ours to overwrite
+        rows, cols = dh.shape
+        db1 = torch.empty(cols, device=dh.device, dtype=dh.dtype)
+        nblk = int(_native.lib.datr_relu_bwd_bias_partial_rows(rows))
+        partial = torch.empty(nblk * cols, device=dh.device, dtype=dh.dtype)
+        with torch.cuda.device(dh.device):
+            rc = _native.lib.datr_relu_bwd_bias_f32(
+                dh.data_ptr(), h.data_ptr(), rows, cols, partial.data_ptr(), db1.data_ptr(),
+                _native.current_stream_ptr(dh.device))
+        _native.check(rc, "relu_bwd_bias")
+        dw1 = dh.t().mm(x2) if need[1] else None
+        dx = dh.mm(w1).view(ctx.shape) if need[0] else None
+        return dx, dw1, (db1 if need[2] else None), dw2, db2
+
+
+def ffn_relu(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear) -> torch.Tensor:
+    """linear2(relu(linear1(x))).  Device float32 tensors take the fused path above; anything
+    else evaluates the reference's own op sequence
+    (/root/reference/models/dino/deformable_transformer.py:803-806)."""
+    if x.is_cuda and x.dtype == torch.float32 and linear1.bias is not None \
+            and linear2.bias is not None and linear1.out_features % 4 == 0:
+        return _FFNRelu.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias)
+    return linear2(torch.relu(linear1(x)))

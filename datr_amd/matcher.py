@@ -7,8 +7,13 @@ assignment per image on the [num_queries, T_i] block.
 
 The assignment itself is the reference's third-party call,
 `scipy.optimize.linear_sum_assignment` (matcher.py:20,94; SciPy un-vendored, unpinned in
-requirements.txt:7).  `solve_lsap` keeps that exact solver so index selection is bit-exact for
-a given cost matrix (BASELINE north_star: "bit-exact query/box index selection").
+requirements.txt:7).  On the host `solve_lsap` keeps that exact solver.  On the device
+`solve_lsap_device` runs the same algorithm (csrc/lsap.hip: SciPy's shortest-augmenting-path
+solver restated, same scan order and tie rule, double arithmetic on the fp32 costs) for every
+problem of the step in one launch and leaves the indices on the device: the reference's seven
+device->host synchronisations per step (matcher.py:91) disappear and index selection stays
+bit-exact for a given cost matrix (BASELINE north_star: "bit-exact query/box index selection";
+tests/test_lsap_gpu.py compares against SciPy, ties included).
 """
 from __future__ import annotations
 
@@ -18,13 +23,64 @@ import torch
 from scipy.optimize import linear_sum_assignment
 from torch import nn
 
-from .boxes import box_cxcywh_to_xyxy, generalized_box_iou
+from .boxes import box_cxcywh_to_xyxy, boxes_are_valid, generalized_box_iou
 
 
 def solve_lsap(cost: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Rectangular linear-sum assignment of a CPU cost matrix -> (row_idx, col_idx) int64."""
     rows, cols = linear_sum_assignment(cost)
     return torch.as_tensor(rows, dtype=torch.int64), torch.as_tensor(cols, dtype=torch.int64)
+
+
+_OFFSETS = {}
+
+
+def _device_offsets(sizes, device) -> torch.Tensor:
+    """[B+1] int32 prefix sums of the per-image box counts, cached per (counts, device)."""
+    key = (tuple(sizes), str(device))
+    t = _OFFSETS.get(key)
+    if t is None:
+        acc = [0]
+        for n in sizes:
+            acc.append(acc[-1] + int(n))
+        t = torch.tensor(acc, dtype=torch.int32).to(device)
+        if len(_OFFSETS) > 256:
+            _OFFSETS.clear()
+        _OFFSETS[key] = t
+    return t
+
+
+def device_lsap_supported(nq: int, sizes) -> bool:
+    return nq <= 1024 and (not sizes or max(sizes) < nq)
+
+
+def solve_lsap_device(C: torch.Tensor, sizes):
+    """C [G, B, nq, sum(sizes)] fp32 on the device -> (q_idx, t_idx, status): q_idx / t_idx
+    [G, sum(sizes)] int64 on the device (image b's pairs at columns offsets[b]:offsets[b+1],
+    query indices ascending -- what SciPy returns), status [G*B] int32 (0 = ok).  No host sync."""
+    from . import _native
+    G, B, nq, Tsum = C.shape
+    dev = C.device
+    q_idx = torch.zeros(G, Tsum, dtype=torch.int64, device=dev)
+    t_idx = torch.zeros(G, Tsum, dtype=torch.int64, device=dev)
+    status = torch.zeros(max(G * B, 1), dtype=torch.int32, device=dev)
+    if G * B == 0 or Tsum == 0:
+        return q_idx, t_idx, status
+    Ct = C.transpose(-1, -2).contiguous()
+    offsets = _device_offsets(sizes, dev)
+    with torch.cuda.device(dev):
+        rc = _native.lib.datr_lsap_f32(Ct.data_ptr(), offsets.data_ptr(), G, B, Tsum, nq,
+                                       max(sizes), q_idx.data_ptr(), t_idx.data_ptr(),
+                                       status.data_ptr(), _native.current_stream_ptr(dev))
+    _native.check(rc, "lsap")
+    return q_idx, t_idx, status
+
+
+class IndexSets(list):
+    """list (per prediction set) of per-image (query_idx, box_idx) pairs, as the reference's
+    matcher returns them, plus `.packed`: the same indices as two [G, sum_i T_i] device tensors
+    when they came from the device solver."""
+    packed = None
 
 
 class HungarianMatcher(nn.Module):
@@ -48,14 +104,47 @@ class HungarianMatcher(nn.Module):
         pos = alpha * ((1 - prob) ** gamma) * (-(prob + 1e-8).log())
         cost_class = pos[:, tgt_ids] - neg[:, tgt_ids]
         cost_bbox = torch.cdist(boxes, tgt_bbox, p=1)
-        cost_giou = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_bbox))
+        xyxy, tgt_xyxy = box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_bbox)
+        if boxes.is_cuda:
+            # box_ops.py:52-53 asserts non-degenerate boxes, which costs two device->host
+            # syncs; on the device the same condition is folded into `poison` instead
+            self._boxes_ok = boxes_are_valid(xyxy) & boxes_are_valid(tgt_xyxy)
+            cost_giou = -generalized_box_iou(xyxy, tgt_xyxy, check=False)
+        else:
+            self._boxes_ok = None
+            cost_giou = -generalized_box_iou(xyxy, tgt_xyxy)
         C = self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
         return C.view(bs, nq, -1)
 
+    # NaN on the device if any assignment problem of the last call was rejected (NaN / -inf
+    # costs -- SciPy raises ValueError for those), else 0: the criterion adds it to the loss so
+    # that a bad matching fails loudly (non-finite loss stops training, engine.py) without a
+    # host synchronisation.  None after host-side matching.
+    poison = None
+    _boxes_ok = None
+
+    def _indices_from_device(self, C, sizes):
+        q_idx, t_idx, status = solve_lsap_device(C, sizes)
+        bad = status.any() if self._boxes_ok is None else (status.any() | ~self._boxes_ok)
+        self.poison = torch.where(bad, float("nan"), 0.0)
+        out = IndexSets()
+        out.packed = (q_idx, t_idx)           # [G, sum T] each, (g, image, ascending query) order
+        for g in range(C.shape[0]):
+            per_image, off = [], 0
+            for n in sizes:
+                per_image.append((q_idx[g, off:off + n], t_idx[g, off:off + n]))
+                off += n
+            out.append(per_image)
+        return out
+
     @torch.no_grad()
     def forward(self, outputs, targets) -> List[Tuple[torch.Tensor, torch.Tensor]]:
-        C = self.cost_matrix(outputs, targets).cpu()
+        C = self.cost_matrix(outputs, targets)
         sizes = [len(v["boxes"]) for v in targets]
+        if C.is_cuda and device_lsap_supported(C.shape[1], sizes):
+            return self._indices_from_device(C[None], sizes)[0]
+        self.poison = None
+        C = C.cpu()
         return [solve_lsap(c[i]) for i, c in enumerate(C.split(sizes, -1))]
 
     @torch.no_grad()
@@ -69,8 +158,12 @@ class HungarianMatcher(nn.Module):
         bs, nq = outputs_list[0]["pred_logits"].shape[:2]
         stacked = {"pred_logits": torch.cat([o["pred_logits"] for o in outputs_list], 0),
                    "pred_boxes": torch.cat([o["pred_boxes"] for o in outputs_list], 0)}
-        C = self.cost_matrix(stacked, targets).view(G, bs, nq, -1).cpu()
+        C = self.cost_matrix(stacked, targets).view(G, bs, nq, -1)
         sizes = [len(v["boxes"]) for v in targets]
+        if C.is_cuda and device_lsap_supported(nq, sizes):
+            return self._indices_from_device(C, sizes)
+        self.poison = None
+        C = C.cpu()
         return [[solve_lsap(c[i]) for i, c in enumerate(C[g].split(sizes, -1))] for g in range(G)]
 
 

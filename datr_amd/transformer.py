@@ -41,6 +41,18 @@ class MLP(nn.Module):
         return x
 
 
+FUSED_FFN = __import__("os").environ.get("DATR_FUSED_FFN", "1") != "0"     # A/B switch
+
+
+def _ffn(x, linear1, activation, dropout, linear2):
+    """linear2(dropout(activation(linear1(x)))) (deformable_transformer.py:803-806, :879-883).
+    ReLU without active dropout on the device takes the fused FFN (datr_amd/fused.py)."""
+    if FUSED_FFN and activation is F.relu and x.is_cuda and not (dropout.training and dropout.p > 0):
+        from .fused import ffn_relu
+        return ffn_relu(x, linear1, linear2)
+    return linear2(dropout(activation(linear1(x))))
+
+
 def _activation(name: str):
     table = {"relu": F.relu, "gelu": F.gelu, "glu": F.glu, "selu": F.selu}
     if name not in table:
@@ -123,7 +135,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         src = self.norm1(src + self.dropout1(
             self.self_attn(q, reference_points, src, spatial_shapes, level_start_index,
                            key_padding_mask)))
-        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        ffn = _ffn(src, self.linear1, self.activation, self.dropout2, self.linear2)
         return self.norm2(src + self.dropout3(ffn))
 
 
@@ -200,7 +212,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.key_aware_proj = None
 
     def forward_ffn(self, tgt):
-        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        tgt2 = _ffn(tgt, self.linear1, self.activation, self.dropout3, self.linear2)
         return self.norm3(tgt + self.dropout4(tgt2))
 
     def forward_sa(self, tgt, query_pos, attn_mask):

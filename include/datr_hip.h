@@ -168,6 +168,41 @@ int datr_conv3x3_forward_f32(const float *x, const float *wt, const float *bias,
                              int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                              float slope, float out_scale, float *y, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * FFN backward, the non-GEMM pass: given h = relu(linear1(x)) saved by the forward and
+ * dh = d loss / d h, computes IN PLACE dh <- dh * (h > 0) and db[c] = sum_r dh[r, c]
+ * (the bias gradient of linear1) in one pass over HBM
+ * (/root/reference/models/dino/deformable_transformer.py:803-806, :879-883 run
+ * threshold_backward and a separate column reduction).  rows x cols fp32 row-major,
+ * cols % 4 == 0.  `partial` is caller-provided scratch of
+ * datr_relu_bwd_bias_partial_rows(rows) * cols floats; the column sum is two-stage and
+ * deterministic (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int64_t datr_relu_bwd_bias_partial_rows(int64_t rows);
+int datr_relu_bwd_bias_f32(float *dh, const float *h, int64_t rows, int64_t cols, float *partial,
+                           float *db, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hungarian matching on the device: all of a step's rectangular assignment problems in one
+ * launch, indices left on the device (no host synchronisation).  Replaces `C.cpu()` +
+ * scipy.optimize.linear_sum_assignment per image (/root/reference/models/dino/matcher.py:91-95);
+ * same algorithm as SciPy's solver (shortest augmenting paths, its scan order and tie rule), in
+ * double on the fp32 costs, so the assignment is identical.
+ *   cost_t   [G, B, Tsum, nc] fp32: the cost matrices TRANSPOSED (row = ground-truth box,
+ *            column = query); problem (g, b) uses rows offsets[b] .. offsets[b+1]-1
+ *   offsets  [B + 1] int32 on the device (prefix sums of the per-image box counts T_b)
+ *   max_rows max_b T_b (host value; sizes the LDS);  requires nc <= 1024 and T_b < nc
+ *            (SciPy transposes exactly the tall problems, T < nc; others: DATR_EUNSUPPORTED)
+ *   q_idx, t_idx [G, Tsum] int64: for problem (g, b), entries offsets[b] + r, r < T_b, hold the
+ *            matched query indices in ascending order and the box (0 .. T_b-1) matched to each --
+ *            SciPy's (row_ind, col_ind) for the [nc x T_b] problem
+ *   status   [G * B] int32: 0 ok, 1 = the matrix held NaN / -inf or was infeasible (outputs
+ *            for that problem are then undefined)
+ * ------------------------------------------------------------------------------------------ */
+int datr_lsap_f32(const float *cost_t, const int32_t *offsets, int64_t G, int64_t B, int64_t Tsum,
+                  int64_t nc, int64_t max_rows, int64_t *q_idx, int64_t *t_idx, int32_t *status,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,3 +81,33 @@ def test_conv3x3_lrelu(shape, slope):
     neg = conv3x3_lrelu(x, w, None, slope=slope, out_scale=-1.0)
     ref2 = -F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=1), slope)
     assert (neg.double() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("rows,d,dff", [(1000, 256, 2048), (37, 64, 128), (2200, 256, 1024), (1, 32, 64)])
+def test_ffn_relu_matches_autograd(rows, d, dff):
+    """Fused FFN (bias+ReLU GEMM epilogue forward; in-place relu-backward + bias-gradient pass
+    backward) vs the reference's op sequence linear2(relu(linear1(x)))
+    (/root/reference/models/dino/deformable_transformer.py:803-806) under autograd."""
+    from datr_amd.fused import ffn_relu
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows)
+    l1, l2 = torch.nn.Linear(d, dff).to(dev), torch.nn.Linear(dff, d).to(dev)
+    x = torch.randn(2, rows, d, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(2, rows, d, generator=g).to(dev)
+    y = ffn_relu(x, l1, l2)
+    y.backward(go)
+    got = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in (*l1.parameters(), *l2.parameters())]
+    x.grad = None
+    for p in (*l1.parameters(), *l2.parameters()):
+        p.grad = None
+    yr = l2(torch.relu(l1(x)))
+    yr.backward(go)
+    ref = [yr.detach(), x.grad] + [p.grad for p in (*l1.parameters(), *l2.parameters())]
+    for a, b in zip(got, ref):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (a.shape, float((a - b).abs().max()), scale)
+    # bias gradient is reproducible bit for bit
+    x.grad = None
+    l1.bias.grad = None
+    ffn_relu(x, l1, l2).backward(go)
+    assert torch.equal(l1.bias.grad, got[3])
