@@ -51,7 +51,9 @@ def synthetic_batch(batch_size, height, width, num_gt, device, seed):
         wh = torch.rand(num_gt, 2, generator=g) * 0.2 + 0.05
         targets.append({"boxes": torch.cat([cxcy, wh], 1).to(device),
                         "labels": torch.randint(1, 9, (num_gt,), generator=g).to(device)})
-    return NestedTensor(imgs.to(device), mask.to(device)), targets
+    # equal-size images: no padded pixel, which the collate function would have recorded
+    # (datr_amd.nested.nested_tensor_from_tensor_list sets `padded` from the image sizes)
+    return NestedTensor(imgs.to(device), mask.to(device), padded=False), targets
 
 
 class Trainer:

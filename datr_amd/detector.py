@@ -165,6 +165,7 @@ class DINO(nn.Module):
     def forward(self, samples: NestedTensor, targets: List = None, self_training_flag=False):
         if isinstance(samples, (list, torch.Tensor)):
             samples = nested_tensor_from_tensor_list(samples)
+        self.transformer.no_padding = getattr(samples, "padded", None) is False
         features, poss = self.backbone(samples)
 
         srcs, masks = [], []

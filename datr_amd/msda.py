@@ -63,6 +63,7 @@ _HOST_META = {}
 # round 1, SLOWER than the row kernel on the encoder call (158 us vs 105 us: four
 # stage -> barrier -> gather -> barrier rounds at 16 waves per CU are latency-bound), so the row
 # kernel stays the default.  DATR_MSDA_TILED_FWD=1 switches it on for A/B measurements.
+MERGE_QUERY_PROJECTIONS = __import__("os").environ.get("DATR_MERGE_QPROJ", "1") != "0"   # A/B switch
 TILED_FORWARD = __import__("os").environ.get("DATR_MSDA_TILED_FWD", "0") == "1"
 
 
@@ -218,8 +219,19 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, Len_in, H, self.d_model // H)
-        offsets = self.sampling_offsets(query).view(N, Len_q, H, self.n_levels, self.n_points, 2)
-        weights = self.attention_weights(query).view(N, Len_q, H, self.n_levels * self.n_points)
+        if query.is_cuda and MERGE_QUERY_PROJECTIONS:
+            # sampling_offsets and attention_weights read the same query: ONE GEMM with the two
+            # weight matrices stacked (N = 384 instead of 256 + 128) forward, and one dgrad / one
+            # wgrad GEMM backward; the parameters stay separate (state_dict, optimizer)
+            w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+            b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+            both = F.linear(query, w, b)
+            n_off = self.sampling_offsets.out_features
+            offsets = both[..., :n_off].view(N, Len_q, H, self.n_levels, self.n_points, 2)
+            weights = both[..., n_off:].reshape(N, Len_q, H, self.n_levels * self.n_points)
+        else:
+            offsets = self.sampling_offsets(query).view(N, Len_q, H, self.n_levels, self.n_points, 2)
+            weights = self.attention_weights(query).view(N, Len_q, H, self.n_levels * self.n_points)
         weights = F.softmax(weights, -1).view(N, Len_q, H, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:
             wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)

@@ -18,13 +18,16 @@ from torch import Tensor
 class NestedTensor:
     """Images zero-padded to a common size plus a bool mask (True = padding)."""
 
-    def __init__(self, tensors: Tensor, mask: Optional[Tensor]):
+    def __init__(self, tensors: Tensor, mask: Optional[Tensor], padded: Optional[bool] = None):
         self.tensors = tensors
         self.mask = mask
+        # host-side knowledge about the mask: False = no pixel is padding (every image already
+        # had the batch's size), True = some are, None = unknown (treated as padded)
+        self.padded = padded
 
     def to(self, device, non_blocking: bool = False) -> "NestedTensor":
         mask = None if self.mask is None else self.mask.to(device, non_blocking=non_blocking)
-        return NestedTensor(self.tensors.to(device, non_blocking=non_blocking), mask)
+        return NestedTensor(self.tensors.to(device, non_blocking=non_blocking), mask, self.padded)
 
     def decompose(self):
         return self.tensors, self.mask
@@ -58,7 +61,8 @@ def nested_tensor_from_tensor_list(tensor_list: Sequence[Tensor]) -> NestedTenso
     for i, img in enumerate(tensor_list):
         batch[i, :, :img.shape[1], :img.shape[2]].copy_(img)
         mask[i, :img.shape[1], :img.shape[2]] = False
-    return NestedTensor(batch, mask)
+    padded = any(img.shape[1] != h or img.shape[2] != w for img in tensor_list)
+    return NestedTensor(batch, mask, padded)
 
 
 def collate_fn_da(batch):

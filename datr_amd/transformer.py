@@ -431,6 +431,12 @@ class DeformableTransformer(nn.Module):
             hit = self._meta_cache[key] = (spatial_shapes, level_start_index)
         return hit
 
+    # Set by the caller (DINO.forward) when the batch is KNOWN on the host to contain no padded
+    # pixel (all images of equal size: `NestedTensor.padded is False`): the attention layers then
+    # skip `value.masked_fill(mask, 0)` (ms_deform_attn.py:101-102), a no-op on an all-False mask
+    # that still costs a pass over value per layer.  Proposals / valid ratios keep using the mask.
+    no_padding = False
+
     def encode(self, srcs, masks, pos_embeds):
         """Flatten the pyramid and run the deformable encoder.  Every encoder operation is
         per-sample, so the source and target halves of a DATR batch can share one call."""
@@ -452,7 +458,8 @@ class DeformableTransformer(nn.Module):
         memory, _, _ = self.encoder(src_flatten, pos=lvl_pos_embed_flatten,
                                     level_start_index=level_start_index,
                                     spatial_shapes=spatial_shapes, valid_ratios=valid_ratios,
-                                    key_padding_mask=mask_flatten, shapes_list=shapes_list)
+                                    key_padding_mask=None if self.no_padding else mask_flatten,
+                                    shapes_list=shapes_list)
         return {"memory": memory, "mask": mask_flatten, "pos": lvl_pos_embed_flatten,
                 "shapes_list": shapes_list, "spatial_shapes": spatial_shapes,
                 "level_start_index": level_start_index, "valid_ratios": valid_ratios}
@@ -507,7 +514,8 @@ class DeformableTransformer(nn.Module):
 
         hs, references = self.decoder(
             tgt=tgt.transpose(0, 1), memory=memory.transpose(0, 1),
-            memory_key_padding_mask=mask_flatten, pos=lvl_pos_embed_flatten.transpose(0, 1),
+            memory_key_padding_mask=None if self.no_padding else mask_flatten,
+            pos=lvl_pos_embed_flatten.transpose(0, 1),
             refpoints_unsigmoid=refpoint_embed.transpose(0, 1),
             level_start_index=level_start_index, spatial_shapes=spatial_shapes,
             valid_ratios=valid_ratios, tgt_mask=attn_mask)
