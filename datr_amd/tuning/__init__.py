@@ -1,5 +1,7 @@
-"""Per-shape GEMM kernel selection for the dense layers of the hot path.
+"""Per-shape library-kernel selection for the dense layers and convolutions of the hot path.
 
+GEMMs
+-----
 The encoder / decoder linears run through hipBLASLt (torch.addmm / mm).  hipBLASLt's default
 heuristic picks kernels that reach ~83 TF/s on the FFN shapes of the 1333x800 step
 ([88892,256]x[256,2048] and friends); PyTorch's TunableOp picks, per shape, the fastest of the
@@ -8,6 +10,17 @@ library's kernels (127-146 TF/s on the same shapes = 81-93 % of the 157 TF/s fp3
 (`python -m datr_amd.tuning.retune`, a couple of minutes); `enable()` loads it with tuning
 switched OFF, so a training run only looks selections up -- shapes that are not in the file
 keep the library default.  Numerics are unchanged: every candidate is a plain fp32 GEMM.
+
+Convolutions
+------------
+PyTorch calls MIOpen in "immediate" mode (`torch.backends.cudnn.benchmark = False`): for a
+problem MIOpen has never measured it falls back to a heuristic solver choice.  `miopen/` holds
+MIOpen's own user find-db / perf-db text files after ONE exhaustive Find run of bench.py's
+1333x800 step on a MI355X (`tools/probes/bench_cudnn_benchmark.py`, ~8 min); `enable()` copies
+them to a writable directory and points `MIOPEN_USER_DB_PATH` at it before the first
+convolution, so immediate mode picks the measured-fastest solver for those shapes
+(117.7 -> 113.0 ms per step).  Other shapes keep MIOpen's defaults; every solver is an fp32
+convolution.
 """
 from __future__ import annotations
 
@@ -17,11 +30,34 @@ import warnings
 import torch
 
 RESULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_mi355x.csv")
+MIOPEN_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen")
+
+
+def enable_miopen_db(src: str = MIOPEN_DB) -> bool:
+    """Point MIOpen's user find-db at a writable copy of the shipped one.  Must run before the
+    process' first convolution (MIOpen reads the variable when it creates its handle); a
+    MIOPEN_USER_DB_PATH the user already set is respected."""
+    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src):
+        return False
+    import shutil
+    import tempfile
+    dst = os.path.join(tempfile.gettempdir(), f"datr_miopen_userdb_{os.getuid()}_{os.getpid()}")
+    try:
+        os.makedirs(dst, exist_ok=True)
+        for name in os.listdir(src):
+            if name.endswith(".txt"):
+                shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
+    except OSError:
+        return False
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return True
 
 
 def enable(path: str = RESULTS, tune: bool = False) -> bool:
     """Turn TunableOp on with the shipped selections.  Returns False (and leaves everything at
     the library defaults) when the file is missing or this build has no TunableOp."""
+    if torch.cuda.is_available():
+        enable_miopen_db()
     if not torch.cuda.is_available() or not hasattr(torch.cuda, "tunable"):
         return False
     t = torch.cuda.tunable
