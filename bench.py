@@ -71,7 +71,7 @@ class Trainer:
         torch.manual_seed(0)
         self.model, self.criterion, _ = build_dino(self.cfg)
         self.model.to(device)
-        if getattr(args, "channels_last", False):
+        if getattr(args, "channels_last", True):
             self.model.backbone.to(memory_format=torch.channels_last)
         self.model.train()
         self.criterion.train()
@@ -206,7 +206,9 @@ def main():
     ap.add_argument("--num-gt", type=int, default=10)
     ap.add_argument("--flat-grads", action="store_true", help="use the flat-bucket reducer at N=1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC backbone")
+    ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
+                    help="keep the backbone in NCHW (default: NHWC / torch.channels_last, which "
+                         "MIOpen's measured-fastest fp32 solvers want; same arithmetic)")
     ap.add_argument("--no-tuned-gemm", dest="tuned_gemm", action="store_false",
                     help="leave hipBLASLt on its default heuristic (datr_amd/tuning)")
     args = ap.parse_args()

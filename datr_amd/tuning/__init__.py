@@ -15,12 +15,13 @@ Convolutions
 ------------
 PyTorch calls MIOpen in "immediate" mode (`torch.backends.cudnn.benchmark = False`): for a
 problem MIOpen has never measured it falls back to a heuristic solver choice.  `miopen/` holds
-MIOpen's own user find-db / perf-db text files after ONE exhaustive Find run of bench.py's
-1333x800 step on a MI355X (`tools/probes/bench_cudnn_benchmark.py`, ~8 min); `enable()` copies
-them to a writable directory and points `MIOPEN_USER_DB_PATH` at it before the first
-convolution, so immediate mode picks the measured-fastest solver for those shapes
-(117.7 -> 113.0 ms per step).  Other shapes keep MIOpen's defaults; every solver is an fp32
-convolution.
+MIOpen's own user find-db / perf-db text files after exhaustive Find runs of bench.py's
+1333x800 step on a MI355X, once with the backbone in NCHW and once in NHWC
+(`tools/probes/bench_cudnn_benchmark.py`, ~8 + 2 min); `enable()` copies them to a writable
+directory and points `MIOPEN_USER_DB_PATH` at it before the first convolution, so immediate
+mode picks the measured-fastest solver for those shapes (117.7 -> 113.0 ms per step in NCHW;
+110.3 ms with the backbone in torch.channels_last, where the NHWC implicit-GEMM solvers need no
+layout transposes).  Other shapes keep MIOpen's defaults; every solver is an fp32 convolution.
 """
 from __future__ import annotations
 

@@ -22,6 +22,7 @@ def main():
     class A:
         flat_grads = False
         tuned_gemm = False
+        channels_last = True
     dev = torch.device("cuda:0")
     tr = bench.Trainer(A, dev, distributed=False)
     for size, b, gt in (((800, 1333), 2, 10), ((640, 640), 1, 5)):

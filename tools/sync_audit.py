@@ -15,7 +15,7 @@ import bench  # noqa: E402
 def main():
     import argparse
     dev = torch.device("cuda:0")
-    args = argparse.Namespace(tuned_gemm=True, channels_last=False, flat_grads=False)
+    args = argparse.Namespace(tuned_gemm=True, channels_last=True, flat_grads=False)
     tr = bench.Trainer(args, dev, False)
     samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
     for _ in range(3):
