@@ -33,13 +33,24 @@ from torch import nn
 
 
 class _Bucket:
+    def view(self, p: nn.Parameter, offset: int) -> torch.Tensor:
+        """The slice of the flat buffer that is `p`'s gradient, with `p`'s own strides: a
+        channels_last conv weight gets a channels_last gradient view (fused AdamW requires
+        parameter and gradient layouts to match; autograd then accumulates without a
+        re-layout)."""
+        dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last) \
+            or (p.dim() == 5 and p.is_contiguous(memory_format=torch.channels_last_3d))
+        if dense:
+            return self.flat.as_strided(p.size(), p.stride(), offset)
+        return self.flat[offset:offset + p.numel()].view_as(p)
+
     def __init__(self, params: List[nn.Parameter], device, dtype):
         self.params = params
         self.numel = sum(p.numel() for p in params)
         self.flat = torch.zeros(self.numel, device=device, dtype=dtype)
         offset = 0
         for p in params:
-            p.grad = self.flat[offset:offset + p.numel()].view_as(p)
+            p.grad = self.view(p, offset)
             offset += p.numel()
         self.pending = len(params)
         self.work = None
@@ -111,9 +122,9 @@ class GradAllReducer:
             b.launched = False
             offset = 0
             for p in b.params:          # re-attach views if something replaced .grad
-                view = b.flat[offset:offset + p.numel()].view_as(p)
-                if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                    p.grad = view
+                if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + b.flat.element_size() * offset \
+                        or p.grad.stride() != p.stride():
+                    p.grad = b.view(p, offset)
                 offset += p.numel()
 
     def finish(self):

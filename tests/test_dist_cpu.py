@@ -111,3 +111,31 @@ def test_reducer_single_process_views_and_unused():
     torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
     opt.step()
     assert not torch.equal(before, model.a.weight)
+
+
+def test_reducer_keeps_channels_last_parameter_layout():
+    """A conv weight in torch.channels_last (bench.py's NHWC backbone) must get a gradient view
+    with the SAME strides: fused AdamW rejects mismatched layouts, and autograd then accumulates
+    the NHWC weight gradient in place.  Values equal the plain (no reducer) gradients."""
+    from datr_amd.dist import GradAllReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(6, 2, 1)).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 4, 5, 7).contiguous(memory_format=torch.channels_last)
+    net(x).square().sum().backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    red = GradAllReducer(net, bucket_mb=0.0005, first_bucket_mb=0.0002)
+    for _ in range(2):                      # second round: views survive zero_grad()
+        red.zero_grad()
+        net(x).square().sum().backward()
+        red.finish()
+        for p, g in zip(net.parameters(), ref):
+            assert p.grad.stride() == p.stride() and p.grad.shape == p.shape
+            torch.testing.assert_close(p.grad, g)
+    w = net[0].weight
+    assert w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous()
+    assert any(b.flat.data_ptr() <= w.grad.data_ptr() < b.flat.data_ptr() + 4 * b.numel
+               for b in red.buckets)          # still a view into a flat bucket
+    torch.optim.AdamW(net.parameters(), lr=1e-3).step()
