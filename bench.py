@@ -36,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
 
 
 def synthetic_batch(batch_size, height, width, num_gt, device, seed):
@@ -148,6 +149,39 @@ class MsdaTimer:
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel": "msda_fwd_rows<8,16> (encoder call)", "launches": len(us),
                 "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
+
+
+def mfma_utilisation(device, rows):
+    """MFMA utilisation of the linears the step spends most of its GEMM time in -- the encoder
+    FFN, [rows, 256] x [256, 2048] and back (54 % of forward FLOPs) -- timed with HIP
+    events on the current stream, after the timed region, against the dense fp32 MFMA peak."""
+    x = torch.randn(rows, 256, device=device)
+    w1 = torch.randn(2048, 256, device=device) * 0.05
+    b1 = torch.zeros(2048, device=device)
+    h = torch._addmm_activation(b1, x, w1.t(), use_gelu=False)
+    dh = torch.randn_like(h)
+    cases = {"linear1 fwd (bias+ReLU epilogue)": lambda: torch._addmm_activation(b1, x, w1.t(), use_gelu=False),
+             "linear1 dgrad": lambda: dh.mm(w1),
+             "linear1 wgrad": lambda: dh.t().mm(x)}
+    flops = 2.0 * rows * 256 * 2048
+    out, total_t = {}, 0.0
+    for name, fn in cases.items():
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        b.record()
+        b.synchronize()
+        t = a.elapsed_time(b) / 10 * 1e-3
+        total_t += t
+        out[name] = round(flops / t / 1e12, 1)
+    achieved = 3 * flops / total_t / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_FP32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP32_PEAK_TFLOPS, 4),
+            "kernel": f"encoder FFN GEMMs, M={rows} N=2048 K=256 (hipBLASLt/rocBLAS, fp32)",
+            "per_gemm_tflops": out}
 
 
 def cpu_baseline():
@@ -265,6 +299,8 @@ def main():
             "pairs_per_sec": round(images / elapsed / 2, 3),
             "roofline": timer.result(),
         }
+        if timer.shape is not None:
+            line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
