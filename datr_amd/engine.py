@@ -187,3 +187,56 @@ def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loa
     resstat = {k: sums[k] / counts[k] for k in sums if counts[k] > 0}
     resstat["_last"] = last
     return resstat
+
+
+@torch.no_grad()
+def evaluate(model, criterion, postprocessors, data_loader, base_ds, device, output_dir=None,
+             wo_class_error=False, args=None, logger=None):
+    """Evaluation loop: counterpart of the reference's `engine.evaluate`
+    (/root/reference/engine.py:349-523) for the 'bbox' post-processor.  Per batch
+    `(samples, _, targets)`: eval-mode forward, criterion (for the logged losses), PostProcess on
+    `orig_size`, results keyed by `image_id` into the evaluator; then cross-rank gather,
+    accumulate, summarize.  `base_ds`: a COCO-format ground-truth dict, or None to take the
+    ground truth from the loop's targets.  Returns (stats, evaluator) with
+    stats['coco_eval_bbox'] = the 12 COCO numbers ([1] = mAP50), as the reference does."""
+    from .evaluation import BoxEvaluator
+    need_tgt_for_training = bool(getattr(args, "use_dn", False))
+    amp = bool(getattr(args, "amp", False))
+    model.eval()
+    criterion.eval()
+    evaluator = BoxEvaluator(base_ds, use_cats=bool(getattr(args, "useCats", True)))
+    sums, counts = defaultdict(float), defaultdict(int)
+    steps = 0
+    for samples, _, targets in data_loader:
+        samples = samples.to(device)
+        targets = [{k: (v.to(device) if torch.is_tensor(v) else v) for k, v in t.items()} for t in targets]
+        with torch.autocast(device_type=torch.device(device).type, enabled=amp):
+            outputs = model(samples, targets) if need_tgt_for_training else model(samples)
+            loss_dict = criterion(outputs, targets)
+        weight_dict = criterion.weight_dict
+        reduced = reduce_dict(loss_dict)
+        scaled = {k: v * weight_dict[k] for k, v in reduced.items() if k in weight_dict}
+        stats = {"loss": float(sum(scaled.values()))}
+        stats.update({k: float(v) for k, v in scaled.items()})
+        stats.update({f"{k}_unscaled": float(v) for k, v in reduced.items()})
+        if "class_error" in reduced and not wo_class_error:
+            stats["class_error"] = float(reduced["class_error"])
+        for k, v in stats.items():
+            sums[k] += v
+            counts[k] += 1
+        orig_target_sizes = torch.stack([t["orig_size"] for t in targets], dim=0)
+        results = postprocessors["bbox"](outputs, orig_target_sizes)
+        res = {int(t["image_id"].reshape(-1)[0]): r for t, r in zip(targets, results)}
+        if base_ds is None:
+            evaluator.add_ground_truth(targets)
+        evaluator.update(res)
+        steps += 1
+        if getattr(args, "debug", False) and steps % 15 == 0:
+            print("BREAK!" * 5)
+            break
+    evaluator.synchronize_between_processes()
+    evaluator.accumulate()
+    evaluator.summarize(verbose=logger is None)
+    out = {k: sums[k] / counts[k] for k in sums if counts[k] > 0}
+    out["coco_eval_bbox"] = list(evaluator.stats)
+    return out, evaluator
