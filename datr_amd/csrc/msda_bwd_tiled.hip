@@ -105,8 +105,8 @@ template <int ABL>
 __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, const DatrTiledMeta meta,
-    int S, int M, int P, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn)
+    int S, int M, int P, int split_levels, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn)
 {
     constexpr int D = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,7 +117,14 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
     float *fctl = reinterpret_cast<float *>(ctl + 16);                             // 32 floats
 
     const int L = meta.L, K = L * P, Lq = meta.Lq;
-    const int bid = blockIdx.x;
+    // small launches (the decoder calls: a few thousand queries) give every target level its own
+    // workgroup -- 4x the parallelism for a grid that would otherwise not fill the chip
+    int bid = blockIdx.x, l_begin = 0, l_end = L;
+    if (split_levels) {
+        l_begin = bid % L;
+        l_end = l_begin + 1;
+        bid /= L;
+    }
     const int m = bid % M;
     const int tile = (bid / M) % meta.total_tiles;
     const int n = bid / (M * meta.total_tiles);
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
 
     DATR_TICK(0);
     const int npairs = nq * P;
-    for (int l = 0; l < L; ++l) {
+    for (int l = l_begin; l < l_end; ++l) {
         const int H = meta.lv[l].H, W = meta.lv[l].W, start = meta.lv[l].start;
         // ---- phase A: pair geometry, corner bounding box, sum |attn| ---------------------------
         if (tid < 4) ctl[tid] = (tid & 1) ? -(1 << 30) : (1 << 30);   // [minx, maxx, miny, maxy]
@@ -277,18 +284,15 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
             const float4 go = f.go, v0 = f.v0, v1 = f.v1, v2 = f.v2, v3 = f.v3;
             const float hh = 1.f - lh, hw = 1.f - lw;
             const float c0 = hh * hw, c1 = hh * lw, c2 = lh * hw, c3 = lh * lw;
-            float pa = go.x * (c0 * v0.x + c1 * v1.x + c2 * v2.x + c3 * v3.x) +
-                       go.y * (c0 * v0.y + c1 * v1.y + c2 * v2.y + c3 * v3.y) +
-                       go.z * (c0 * v0.z + c1 * v1.z + c2 * v2.z + c3 * v3.z) +
-                       go.w * (c0 * v0.w + c1 * v1.w + c2 * v2.w + c3 * v3.w);
-            float pw = go.x * (hh * (v1.x - v0.x) + lh * (v3.x - v2.x)) +
-                       go.y * (hh * (v1.y - v0.y) + lh * (v3.y - v2.y)) +
-                       go.z * (hh * (v1.z - v0.z) + lh * (v3.z - v2.z)) +
-                       go.w * (hh * (v1.w - v0.w) + lh * (v3.w - v2.w));
-            float ph = go.x * (hw * (v2.x - v0.x) + lw * (v3.x - v1.x)) +
-                       go.y * (hw * (v2.y - v0.y) + lw * (v3.y - v1.y)) +
-                       go.z * (hw * (v2.z - v0.z) + lw * (v3.z - v1.z)) +
-                       go.w * (hw * (v2.w - v0.w) + lw * (v3.w - v1.w));
+            // per-corner partial dot products <grad_out, v_c> over this lane's 4 channels; the
+            // bilinear combinations below are linear in them (16 + 12 flops instead of 60)
+            const float d0 = go.x * v0.x + go.y * v0.y + go.z * v0.z + go.w * v0.w;
+            const float d1 = go.x * v1.x + go.y * v1.y + go.z * v1.z + go.w * v1.w;
+            const float d2 = go.x * v2.x + go.y * v2.y + go.z * v2.z + go.w * v2.w;
+            const float d3 = go.x * v3.x + go.y * v3.y + go.z * v3.z + go.w * v3.w;
+            float pa = c0 * d0 + c1 * d1 + c2 * d2 + c3 * d3;
+            float pw = hh * (d1 - d0) + lh * (d3 - d2);
+            float ph = hw * (d2 - d0) + lw * (d3 - d1);
             pa = row_sum8(pa);
             pw = row_sum8(pw) * aW;
             ph = row_sum8(ph) * aH;
@@ -302,6 +306,8 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
             // d out / d value: a * corner weight * grad_out, into the window (fixed point) or,
             // for a corner that fell outside it, straight to global memory
             const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
+            // pre-scaled for the fixed-point path: one multiply + one convert per channel and corner
+            const float4 gs = make_float4(ga.x * scale, ga.y * scale, ga.z * scale, ga.w * scale);
             const int ry = y0 - wy0, rx = x0 - wx0;
 #define DATR_CORNER(BIT, DY, DX, C, OFF)                                                        \
             if (ok & (BIT)) {                                                                   \
@@ -314,10 +320,10 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
                        signed sum; a negative lo borrows from hi and phase C undoes it */       \
                     unsigned long long *dst =                                                   \
                         reinterpret_cast<unsigned long long *>(win + r * D + j * 4);            \
-                    const long long p01 = (long long)__float2int_rn((C) * ga.x * scale) +       \
-                        ((long long)__float2int_rn((C) * ga.y * scale) << 32);                  \
-                    const long long p23 = (long long)__float2int_rn((C) * ga.z * scale) +       \
-                        ((long long)__float2int_rn((C) * ga.w * scale) << 32);                  \
+                    const long long p01 = (long long)__float2int_rn((C) * gs.x) +               \
+                        ((long long)__float2int_rn((C) * gs.y) << 32);                          \
+                    const long long p23 = (long long)__float2int_rn((C) * gs.z) +               \
+                        ((long long)__float2int_rn((C) * gs.w) << 32);                          \
                     atomicAdd(dst + 0, (unsigned long long)p01);                                \
                     atomicAdd(dst + 1, (unsigned long long)p23);                                \
                     if (j == 0) touched[r] = 1;                                                 \
@@ -375,14 +381,16 @@ extern "C" int datr_internal_msda_bwd_tiled_d32(
     const DatrTiledMeta *meta, int64_t N, int64_t S, int64_t M, int64_t P,
     float *grad_value, float *grad_loc, float *grad_attn, void *stream)
 {
-    const int64_t blocks = N * M * meta->total_tiles;
+    int64_t blocks = N * M * meta->total_tiles;
     if (blocks <= 0 || blocks > 0x7fffffff) return DATR_EUNSUPPORTED;
+    const int split_levels = blocks < 1024 && meta->L > 1;       // < 2 workgroups per CU x 2 rounds
+    if (split_levels) blocks *= meta->L;
     const size_t lds = kMaxPairs * sizeof(PairGeom) + (size_t)kWinRows * 32 * 4 +
                        ((kWinRows + 15) & ~15) + 48 * 4;
 #define DATR_LAUNCH_TILED(A)                                                                     \
     hipLaunchKernelGGL(msda_bwd_tiled_d32<A>, dim3((unsigned)blocks), dim3(kThreads), lds,         \
                        (hipStream_t)stream, grad_out, value, loc, attn, *meta, (int)S, (int)M,     \
-                       (int)P, grad_value, grad_loc, grad_attn)
+                       (int)P, split_levels, grad_value, grad_loc, grad_attn)
 #ifdef DATR_PROBE
     static const int abl = getenv("DATR_MSDA_ABLATE") ? atoi(getenv("DATR_MSDA_ABLATE")) : 0;
     switch (abl) {

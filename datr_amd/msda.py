@@ -63,6 +63,7 @@ _HOST_META = {}
 # round 1, SLOWER than the row kernel on the encoder call (158 us vs 105 us: four
 # stage -> barrier -> gather -> barrier rounds at 16 waves per CU are latency-bound), so the row
 # kernel stays the default.  DATR_MSDA_TILED_FWD=1 switches it on for A/B measurements.
+TILED_BACKWARD_MIN_LQ = int(__import__("os").environ.get("DATR_MSDA_TILED_BWD_MIN_LQ", "64"))
 MERGE_QUERY_PROJECTIONS = __import__("os").environ.get("DATR_MERGE_QPROJ", "1") != "0"   # A/B switch
 TILED_FORWARD = __import__("os").environ.get("DATR_MSDA_TILED_FWD", "0") == "1"
 
@@ -127,7 +128,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
         stream = _native.current_stream_ptr(value.device)
-        if sfx == "f32" and D == 32 and Lq >= 64:
+        if sfx == "f32" and D == 32 and Lq >= TILED_BACKWARD_MIN_LQ:
             # query-tiled backward (LDS accumulation): needs the geometry on the host
             sh_host, ls_host = _host_meta(shapes, lsi)
             rc = _native.lib.datr_msda_backward_tiled_f32(
