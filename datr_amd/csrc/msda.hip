@@ -657,6 +657,13 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
                                       Lq, P, grad_value, grad_loc, grad_attn, stream);
     if (!grad_out || !value || !loc || !attn || !grad_value || !grad_loc || !grad_attn)
         return DATR_EINVAL;
+    // few, spatially unordered queries (the decoder's cross-attention): workgroups own ranges of
+    // value rows and scan the samples -- no global atomics, no zero-fill (msda_bwd_owner.hip)
+    if (Lq != S && Lq <= 4096) {
+        const int rc = datr_internal_msda_bwd_owner_d32(grad_out, value, loc, attn, &meta, N, S, M, P,
+                                                        Lq, grad_value, grad_loc, grad_attn, stream);
+        if (rc != DATR_EUNSUPPORTED) return rc;
+    }
     if (hipMemsetAsync(grad_value, 0, (size_t)(N * S * M * D) * sizeof(float),
                        (hipStream_t)stream) != hipSuccess)
         return DATR_ELAUNCH;

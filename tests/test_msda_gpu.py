@@ -321,3 +321,35 @@ def test_full_size_subsample_against_oracle(M, O, dev):
     torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
     keep = off_grid(loc, sh)
     torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
+
+
+@pytest.mark.parametrize("mode", ["clustered", "spread"])
+def test_owner_backward_for_decoder_queries(M, O, dev, mode, monkeypatch):
+    """Lq != S, a few hundred queries: workgroups own ranges of value rows (msda_bwd_owner.hip).
+    `clustered` piles every query onto the same few pixels (the contention case the kernel
+    exists for), `spread` scatters them over all levels / ranges.  The output buffers are
+    pre-filled with NaN: the kernel must write every element itself (it does no zero-fill)."""
+    shapes = [(40, 53), (20, 27), (10, 14), (5, 7)]               # level 0: 2120 rows = 5 ranges
+    N, Lq, Mh, D, P = 2, 333, 8, 32, 4
+    value, sh, lsi, loc, attn = O.random_inputs(N, Lq, Mh, D, shapes, P, seed=21, loc_range=(-0.1, 1.1))
+    if mode == "clustered":
+        g = torch.Generator().manual_seed(4)
+        loc = (0.37 + 0.01 * torch.randn(loc.shape, generator=g)).contiguous()
+    go = torch.randn(N, Lq, Mh * D, generator=torch.Generator().manual_seed(9)) * 2.0
+    real_empty = torch.empty_like
+
+    def nan_empty(t, **kw):
+        out = real_empty(t, **kw)
+        return out.fill_(float("nan")) if out.is_floating_point() and out.is_cuda else out
+    monkeypatch.setattr(torch, "empty_like", nan_empty)
+    out, gv, gl, ga = run_hip(M, dev, value, sh, lsi, loc, attn, go)
+    monkeypatch.setattr(torch, "empty_like", real_empty)
+    rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
+    assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+    scale = float(rv.abs().max())
+    # fixed-point step = max|grad_out| * sum|attn over the level| / 2^30 (~3e-7 of max|grad_value|
+    # here); ~150 contributions meet on a row of the 5x7 level: allow 5e-6 of the maximum
+    torch.testing.assert_close(gv, rv, rtol=1e-4, atol=5e-6 * scale)
+    torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
+    keep = off_grid(loc, sh, eps=1e-4)
+    torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
