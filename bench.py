@@ -86,8 +86,8 @@ class Trainer:
     def step(self, samples, targets):
         out = self.model(samples, targets)
         loss_dict = self.criterion(out, targets)
-        wd = self.criterion.weight_dict
-        loss = sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
+        from datr_amd.criterion import weighted_total
+        loss = weighted_total(loss_dict, self.criterion.weight_dict)
         if self.reducer is not None:
             self.reducer.zero_grad()
         else:

@@ -193,7 +193,7 @@ class Backbone(nn.Module):
         assert m is not None
         for name, x in feats.items():
             mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
-            out[name] = NestedTensor(x, mask)
+            out[name] = NestedTensor(x, mask, tensor_list.padded)
         return out
 
 
@@ -211,10 +211,25 @@ class PositionEmbeddingSineHW(nn.Module):
         self.temperatureH, self.temperatureW = temperatureH, temperatureW
         self.normalize = normalize
         self.scale = 2 * math.pi if scale is None else scale
+        self._cache = {}
 
     def forward(self, tensor_list: NestedTensor):
         x, mask = tensor_list.tensors, tensor_list.mask
         assert mask is not None
+        if getattr(tensor_list, "padded", None) is False:
+            # no padded pixel (known on the host): the embedding depends on the shape only --
+            # computed once per (N, H, W) instead of ~15 launches per level and pass
+            key = (tuple(mask.shape), str(x.device), self.num_pos_feats, self.temperatureH,
+                   self.temperatureW, self.normalize, self.scale)
+            hit = self._cache.get(key)
+            if hit is None:
+                if len(self._cache) >= 16:
+                    self._cache.clear()
+                hit = self._cache[key] = self._embed(x, mask).detach()
+            return hit
+        return self._embed(x, mask)
+
+    def _embed(self, x, mask):
         valid = ~mask
         y_embed = valid.cumsum(1, dtype=torch.float32)
         x_embed = valid.cumsum(2, dtype=torch.float32)

@@ -44,6 +44,21 @@ def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: f
 _STATIC = {}
 
 
+def weighted_total(loss_dict, weight_dict):
+    """sum_k loss_dict[k] * weight_dict[k] over the keys present in both, in loss_dict's order
+    (/root/reference/engine.py:77: `sum(loss_dict[k] * weight_dict[k] for k in ...)`), evaluated
+    as ONE stacked dot product: 3 launches instead of 2 x 82, and 3 instead of ~330 autograd nodes
+    in backward.  d total / d loss_k = weight_k exactly, as in the reference's chain of adds."""
+    keys = [k for k in loss_dict.keys() if k in weight_dict]
+    if not keys:
+        return 0
+    vals = torch.stack([loss_dict[k] for k in keys])
+    w = _cached(("w", tuple(keys), tuple(float(weight_dict[k]) for k in keys), str(vals.device),
+                 vals.dtype), lambda: torch.tensor([float(weight_dict[k]) for k in keys],
+                                                   dtype=vals.dtype).to(vals.device))
+    return (vals * w).sum()
+
+
 def _cached(key, make):
     t = _STATIC.get(key)
     if t is None:

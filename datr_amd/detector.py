@@ -177,7 +177,7 @@ class DINO(nn.Module):
         for lvl in range(len(srcs), self.num_feature_levels):
             src = self.input_proj[lvl](features[-1].tensors if lvl == len(features) else srcs[-1])
             mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
-            poss.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+            poss.append(self.backbone[1](NestedTensor(src, mask, getattr(samples, "padded", None))).to(src.dtype))
             srcs.append(src)
             masks.append(mask)
 

@@ -14,6 +14,7 @@ from typing import Iterable
 
 import torch
 
+from .criterion import weighted_total
 from .nested import reduce_dict
 
 
@@ -52,7 +53,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             outputs = model(samples, targets) if need_tgt_for_training else model(samples)
             loss_dict = criterion(outputs, targets)
             weight_dict = criterion.weight_dict
-            losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+            losses = weighted_total(loss_dict, weight_dict)
 
         loss_dict_reduced = reduce_dict(loss_dict)
         scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
@@ -149,8 +150,8 @@ def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loa
             weight_dict = criterion.weight_dict
             loss_dict_source = criterion(source_outputs, source_labels, target_domain_flag=False)
             loss_dict_target = criterion(valid_target_outputs, pseudo_list, target_domain_flag=True)
-            losses_source = sum(loss_dict_source[k] * weight_dict[k] for k in loss_dict_source if k in weight_dict)
-            losses_target = sum(loss_dict_target[k] * weight_dict[k] for k in loss_dict_target if k in weight_dict)
+            losses_source = weighted_total(loss_dict_source, weight_dict)
+            losses_target = weighted_total(loss_dict_target, weight_dict)
             if isinstance(losses_target, int) and losses_target == 0:
                 losses_target = torch.tensor(0)
             losses = losses_source + losses_target * weight_dict["loss_self_training"]
