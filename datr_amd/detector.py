@@ -77,6 +77,7 @@ class DINO(nn.Module):
         # one encoder call for source+target (same values up to fp32 GEMM blocking); False
         # reproduces the reference's two separate transformer calls exactly
         self.merge_encoder_passes = True
+        self.merge_decoder_passes = True      # with merge_encoder_passes: one decoder pass too
         self.dn_noise_override = None        # tests inject the reference's RNG draws here
 
         if num_feature_levels > 1:
@@ -205,8 +206,33 @@ class DINO(nn.Module):
             half = srcs_all[0].shape[0] // 2
             enc_src = self.transformer.slice_encoded(enc_all, slice(0, half))
             enc_tgt = self.transformer.slice_encoded(enc_all, slice(half, None))
-            hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer.decode(
-                enc_src, input_query_bbox, input_query_label, attn_mask)
+            if self.merge_decoder_passes:
+                # ONE decoder pass for all 2B images as well.  The target images get the source's
+                # de-noising slots as placeholders: the attention mask already forbids matching
+                # queries to look at DN slots (dn_components.py:117-124), every other decoder
+                # operation is per query, so the target's 900 matching queries come out exactly
+                # as in a separate mask-free pass (dino.py:380-381); the placeholder outputs are
+                # dropped.  Half the launches of the launch-bound decoder, larger GEMMs.
+                if input_query_bbox is not None:
+                    q_bbox = torch.cat([input_query_bbox, input_query_bbox.detach()], 0)
+                    q_label = torch.cat([input_query_label, input_query_label.detach()], 0)
+                    dn_pad = input_query_bbox.shape[1]
+                else:
+                    q_bbox = q_label = None
+                    dn_pad = 0
+                hs_a, ref_a, hs_enc_a, ref_enc_a, ibp_a = self.transformer.decode(
+                    enc_all, q_bbox, q_label, attn_mask)
+                hs, reference = [h[:half] for h in hs_a], [r[:half] for r in ref_a]
+                hs_enc = None if hs_enc_a is None else hs_enc_a[:, :half]
+                ref_enc = None if ref_enc_a is None else ref_enc_a[:, :half]
+                init_box_proposal = ibp_a[:half]
+                target_pass = ([h[half:, dn_pad:] for h in hs_a], [r[half:, dn_pad:] for r in ref_a],
+                               None if hs_enc_a is None else hs_enc_a[:, half:],
+                               None if ref_enc_a is None else ref_enc_a[:, half:], ibp_a[half:])
+            else:
+                target_pass = None
+                hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer.decode(
+                    enc_src, input_query_bbox, input_query_label, attn_mask)
         else:
             hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer(
                 srcs, masks, input_query_bbox, poss, input_query_label, attn_mask)
@@ -241,7 +267,9 @@ class DINO(nn.Module):
             self.global_proto, self.Amount = g_proto, g_amount
 
             # second transformer pass: target half, no DN queries, no attention mask
-            if merged:
+            if merged and target_pass is not None:
+                hs_t, reference_t, hs_enc_t, ref_enc_t, init_box_proposal_t = target_pass
+            elif merged:
                 hs_t, reference_t, hs_enc_t, ref_enc_t, init_box_proposal_t = \
                     self.transformer.decode(enc_tgt, None, None, None)
             else:

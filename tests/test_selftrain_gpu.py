@@ -30,6 +30,8 @@ def test_teacher_student_step_on_device():
     state = {"i": 0}
 
     def student_selection(scores):
+        if scores.shape[0] == student_calls[0].shape[0] + student_calls[1].shape[0]:
+            return torch.cat(student_calls, 0)         # merged source + target decoder pass
         idx = student_calls[state["i"] % 2]
         state["i"] += 1
         return idx
