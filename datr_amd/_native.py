@@ -33,6 +33,8 @@ _SIGNATURES = {
     "datr_affine_act_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
     "datr_conv3x3_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
                                  ctypes.c_float, _vp, _vp],
+    "datr_add_layernorm_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp],
+    "datr_add_layernorm_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "datr_lsap_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_focal_loss_forward_f32": [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
@@ -60,6 +62,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_strerror.argtypes = [ctypes.c_int]
     lib.datr_focal_scratch_floats.restype = ctypes.c_int64
     lib.datr_focal_scratch_floats.argtypes = [_i64, _i64]
+    lib.datr_add_layernorm_partial_floats.restype = ctypes.c_int64
+    lib.datr_add_layernorm_partial_floats.argtypes = [_i64]
     lib.datr_relu_bwd_bias_partial_rows.restype = ctypes.c_int64
     lib.datr_relu_bwd_bias_partial_rows.argtypes = [_i64]
     for name, argtypes in _SIGNATURES.items():

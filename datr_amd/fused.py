@@ -139,3 +139,68 @@ def ffn_relu(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear
             and linear2.bias is not None and linear1.out_features % 4 == 0:
         return _FFNRelu.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias)
     return linear2(torch.relu(linear1(x)))
+
+
+class _AddLayerNorm(Function):
+    """y = LayerNorm(x + res) (C = 256), forward and backward one HBM pass each
+    (csrc/layernorm.hip).  Saves x, res, mean, rstd -- the same bytes autograd's own graph keeps
+    (the sum) -- and recomputes x + res in backward."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        r2 = None
+        if res is not None:
+            r2 = res.reshape(-1, C)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _native.lib.datr_add_layernorm_forward_f32(
+                x2.data_ptr(), 0 if r2 is None else r2.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                rows, C, float(eps), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                _native.current_stream_ptr(x.device))
+        _native.check(rc, "add_layernorm_forward")
+        ctx.save_for_backward(x2, r2, mean, rstd, gamma)
+        ctx.shape = shape
+        ctx.res_shape = None if res is None else res.shape
+        return y.view(shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, r2, mean, rstd, gamma = ctx.saved_tensors
+        rows, C = x2.shape
+        dy2 = dy.reshape(-1, C)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = torch.empty_like(x2)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        partial = torch.empty(int(_native.lib.datr_add_layernorm_partial_floats(rows)),
+                              device=x2.device, dtype=torch.float32)
+        with torch.cuda.device(x2.device):
+            rc = _native.lib.datr_add_layernorm_backward_f32(
+                dy2.data_ptr(), x2.data_ptr(), 0 if r2 is None else r2.data_ptr(), mean.data_ptr(),
+                rstd.data_ptr(), gamma.data_ptr(), rows, C, dx.data_ptr(), partial.data_ptr(),
+                dgamma.data_ptr(), dbeta.data_ptr(), _native.current_stream_ptr(x2.device))
+        _native.check(rc, "add_layernorm_backward")
+        dxv = dx.view(ctx.shape)
+        dres = None if r2 is None else dx.view(ctx.res_shape)
+        return dxv, dres, dgamma, dbeta, None
+
+
+def add_layer_norm(x: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
+    """norm(x + res) -- the tail of every post-norm sub-block
+    (/root/reference/models/dino/deformable_transformer.py:796-806, :856-893).  Device float32
+    tensors with 256 channels and an affine LayerNorm take the fused kernels; anything else
+    evaluates the reference's two ops."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and x.shape == res.shape \
+            and norm.elementwise_affine and norm.bias is not None \
+            and tuple(norm.normalized_shape) == (256,):
+        return _AddLayerNorm.apply(x, res, norm.weight, norm.bias, norm.eps)
+    return norm(x + res)

@@ -41,6 +41,18 @@ class MLP(nn.Module):
         return x
 
 
+FUSED_ADD_NORM = __import__("os").environ.get("DATR_FUSED_ADD_NORM", "1") != "0"   # A/B switch
+
+
+def _add_norm(x, branch, dropout, norm):
+    """norm(x + dropout(branch)) (deformable_transformer.py:796-806, :856-893); on the device the
+    add and the LayerNorm are one pass each way (datr_amd/fused.py::add_layer_norm)."""
+    if FUSED_ADD_NORM and x.is_cuda and not (dropout.training and dropout.p > 0):
+        from .fused import add_layer_norm
+        return add_layer_norm(branch, x, norm)
+    return norm(x + dropout(branch))
+
+
 FUSED_FFN = __import__("os").environ.get("DATR_FUSED_FFN", "1") != "0"     # A/B switch
 
 
@@ -132,11 +144,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
                 key_padding_mask=None):
         q = src if pos is None else src + pos
-        src = self.norm1(src + self.dropout1(
-            self.self_attn(q, reference_points, src, spatial_shapes, level_start_index,
-                           key_padding_mask)))
+        src = _add_norm(src, self.self_attn(q, reference_points, src, spatial_shapes,
+                                            level_start_index, key_padding_mask),
+                        self.dropout1, self.norm1)
         ffn = _ffn(src, self.linear1, self.activation, self.dropout2, self.linear2)
-        return self.norm2(src + self.dropout3(ffn))
+        return _add_norm(src, ffn, self.dropout3, self.norm2)
 
 
 class TransformerEncoder(nn.Module):
@@ -213,12 +225,12 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         tgt2 = _ffn(tgt, self.linear1, self.activation, self.dropout3, self.linear2)
-        return self.norm3(tgt + self.dropout4(tgt2))
+        return _add_norm(tgt, tgt2, self.dropout4, self.norm3)
 
     def forward_sa(self, tgt, query_pos, attn_mask):
         q = k = tgt if query_pos is None else tgt + query_pos
         tgt2 = self.self_attn(q, k, tgt, attn_mask=attn_mask, need_weights=False)[0]
-        return self.norm2(tgt + self.dropout2(tgt2))
+        return _add_norm(tgt, tgt2, self.dropout2, self.norm2)
 
     def forward_ca(self, tgt, query_pos, reference_points, memory, spatial_shapes,
                    level_start_index, key_padding_mask):
@@ -226,7 +238,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         tgt2 = self.cross_attn(q.transpose(0, 1), reference_points.transpose(0, 1).contiguous(),
                                memory.transpose(0, 1), spatial_shapes, level_start_index,
                                key_padding_mask).transpose(0, 1)
-        return self.norm1(tgt + self.dropout1(tgt2))
+        return _add_norm(tgt, tgt2, self.dropout1, self.norm1)
 
     def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None,
                 tgt_key_padding_mask=None, tgt_reference_points=None, memory=None,

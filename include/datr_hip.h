@@ -203,6 +203,24 @@ int datr_lsap_f32(const float *cost_t, const int32_t *offsets, int64_t G, int64_
                   int64_t nc, int64_t max_rows, int64_t *q_idx, int64_t *t_idx, int32_t *status,
                   void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Residual add + LayerNorm over C = 256 channels (the post-norm tail of every transformer
+ * sub-block, /root/reference/models/dino/deformable_transformer.py:796-806, :856-893):
+ *   forward   y = LayerNorm(x + res) * gamma + beta; also writes mean / rstd [rows]
+ *   backward  dx = d loss / d x = d loss / d res (x + res is recomputed, not stored), and
+ *             dgamma / dbeta [C] through caller-provided scratch `partial` of
+ *             datr_add_layernorm_partial_floats(rows) floats (deterministic, no atomics)
+ * `res` may be NULL (plain LayerNorm).  rows x C fp32 row-major; C != 256: DATR_EUNSUPPORTED.
+ * ------------------------------------------------------------------------------------------ */
+int64_t datr_add_layernorm_partial_floats(int64_t rows);
+int datr_add_layernorm_forward_f32(const float *x, const float *res, const float *gamma,
+                                   const float *beta, int64_t rows, int64_t C, float eps, float *y,
+                                   float *mean, float *rstd, void *stream);
+int datr_add_layernorm_backward_f32(const float *dy, const float *x, const float *res,
+                                    const float *mean, const float *rstd, const float *gamma,
+                                    int64_t rows, int64_t C, float *dx, float *partial, float *dgamma,
+                                    float *dbeta, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

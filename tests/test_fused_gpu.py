@@ -111,3 +111,33 @@ def test_ffn_relu_matches_autograd(rows, d, dff):
     l1.bias.grad = None
     ffn_relu(x, l1, l2).backward(go)
     assert torch.equal(l1.bias.grad, got[3])
+
+
+@pytest.mark.parametrize("shape", [(2, 1000, 256), (1100, 4, 256), (3, 256), (1, 1, 256)])
+def test_add_layer_norm_matches_autograd(shape):
+    """Fused residual add + LayerNorm (csrc/layernorm.hip) vs norm(x + res) under autograd
+    (/root/reference/models/dino/deformable_transformer.py:796-806)."""
+    from datr_amd.fused import add_layer_norm
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(shape[0])
+    norm = torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(256, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(256, generator=g))
+    x = (torch.randn(shape, generator=g) * 2 + 0.3).to(dev).requires_grad_(True)
+    r = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(shape, generator=g).to(dev)
+    y = add_layer_norm(x, r, norm)
+    y.backward(go)
+    got = [y.detach().clone(), x.grad.clone(), r.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()]
+    x.grad = r.grad = norm.weight.grad = norm.bias.grad = None
+    yr = norm(x + r)
+    yr.backward(go)
+    ref = [yr.detach(), x.grad, r.grad, norm.weight.grad, norm.bias.grad]
+    for a, b in zip(got, ref):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-6, (a.shape, float((a - b).abs().max()), scale)
+    # gamma / beta gradients are reproducible bit for bit
+    x.grad = r.grad = norm.weight.grad = norm.bias.grad = None
+    add_layer_norm(x, r, norm).backward(go)
+    assert torch.equal(norm.weight.grad, got[3]) and torch.equal(norm.bias.grad, got[4])

@@ -1,0 +1,21 @@
+"""Is the step CPU-bound?  Host time to ENQUEUE 20 steps vs time until the GPU has finished them."""
+import os, sys, time, argparse
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+args = argparse.Namespace(tuned_gemm=True, channels_last=True, flat_grads=False)
+dev = torch.device("cuda:0")
+tr = bench.Trainer(args, dev, False)
+samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
+samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
+for _ in range(6):
+    tr.step(samples, targets)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    tr.step(samples, targets)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"enqueue {1e3 * (t1 - t0) / 20:.1f} ms/step, complete {1e3 * (t2 - t0) / 20:.1f} ms/step, "
+      f"GPU backlog at the end {1e3 * (t2 - t1):.1f} ms")
