@@ -162,3 +162,28 @@ def test_source_only_switch(monkeypatch):
     assert "da_output" not in out
     losses = criterion(out, targets)
     assert "loss_backbone_DA" not in losses and "loss_ce_dn_4" in losses
+
+
+def test_no_padding_fast_path_is_identical(monkeypatch):
+    """Equal-size images: `nested_tensor_from_tensor_list` records padded=False on the host and
+    the model skips the all-False `masked_fill` and re-uses cached position embeddings
+    (datr_amd/transformer.py no_padding, backbone.PositionEmbeddingSineHW).  Outputs must equal
+    the generic path (padded unknown) bit for bit, also on the second (cached) call."""
+    patch_msda_with_oracle(monkeypatch, kind="c")
+    from datr_amd.nested import NestedTensor, nested_tensor_from_tensor_list
+    _, model, _, _ = build_model()
+    model.eval()
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.randn(3, 192, 256, generator=g) for _ in range(2)]
+    fast = nested_tensor_from_tensor_list(imgs)
+    assert fast.padded is False
+    generic = NestedTensor(fast.tensors, fast.mask, None)
+    with torch.no_grad():
+        ref = model(generic)
+        a = model(fast)
+        b = model(fast)                       # position embeddings now come from the cache
+    for out in (a, b):
+        assert torch.equal(out["pred_logits"], ref["pred_logits"])
+        assert torch.equal(out["pred_boxes"], ref["pred_boxes"])
+    mixed = nested_tensor_from_tensor_list([imgs[0], imgs[1][:, :150, :200]])
+    assert mixed.padded is True
