@@ -171,6 +171,25 @@ def _is_power_of_2(n: int) -> bool:
     return n != 0 and (n & (n - 1)) == 0
 
 
+_INV_WH = {}
+
+
+def _inverse_wh(spatial_shapes: torch.Tensor, n_heads: int, n_points: int) -> torch.Tensor:
+    """[n_heads * L * n_points * 2] vector of 1/W_l, 1/H_l in the layout of the sampling_offsets
+    output (head, level, point, xy); cached per geometry tensor (transformer._level_meta keeps
+    one tensor per pyramid geometry alive, so the pointer identifies it)."""
+    key = (spatial_shapes.data_ptr(), str(spatial_shapes.device), n_heads, n_points,
+           tuple(spatial_shapes.shape))
+    inv = _INV_WH.get(key)
+    if inv is None:
+        if len(_INV_WH) > 64:
+            _INV_WH.clear()
+        wh = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1).to(torch.float32)
+        inv = (1.0 / wh)[None, :, None, :].expand(n_heads, -1, n_points, -1).reshape(-1).contiguous()
+        _INV_WH[key] = inv
+    return inv
+
+
 class MSDeformAttn(nn.Module):
     """Same constructor, parameter names (state_dict keys `sampling_offsets`,
     `attention_weights`, `value_proj`, `output_proj`), initialisation and forward signature as
@@ -220,12 +239,22 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, Len_in, H, self.d_model // H)
+        fold_wh = False
         if query.is_cuda and MERGE_QUERY_PROJECTIONS:
             # sampling_offsets and attention_weights read the same query: ONE GEMM with the two
             # weight matrices stacked (N = 384 instead of 256 + 128) forward, and one dgrad / one
             # wgrad GEMM backward; the parameters stay separate (state_dict, optimizer)
-            w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
-            b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+            w_off, b_off = self.sampling_offsets.weight, self.sampling_offsets.bias
+            if reference_points.shape[-1] == 2:
+                # 2-d reference points (encoder): offsets are divided by (W_l, H_l) per level.
+                # Scaling the 256 rows of the small weight matrix instead folds that division --
+                # and its backward -- into the GEMM: two passes over the [N, Lq, 256] offsets
+                # less per layer and direction.  (q W) s == q (W s) up to fp32 rounding.
+                inv = _inverse_wh(input_spatial_shapes, H, self.n_points)
+                w_off, b_off = w_off * inv[:, None], b_off * inv
+                fold_wh = True
+            w = torch.cat([w_off, self.attention_weights.weight], 0)
+            b = torch.cat([b_off, self.attention_weights.bias], 0)
             both = F.linear(query, w, b)
             n_off = self.sampling_offsets.out_features
             offsets = both[..., :n_off].view(N, Len_q, H, self.n_levels, self.n_points, 2)
@@ -234,7 +263,9 @@ class MSDeformAttn(nn.Module):
             offsets = self.sampling_offsets(query).view(N, Len_q, H, self.n_levels, self.n_points, 2)
             weights = self.attention_weights(query).view(N, Len_q, H, self.n_levels * self.n_points)
         weights = F.softmax(weights, -1).view(N, Len_q, H, self.n_levels, self.n_points)
-        if reference_points.shape[-1] == 2:
+        if reference_points.shape[-1] == 2 and fold_wh:
+            locations = reference_points[:, :, None, :, None, :] + offsets
+        elif reference_points.shape[-1] == 2:
             wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
             locations = reference_points[:, :, None, :, None, :] \
                 + offsets / wh[None, None, None, :, None, :]
