@@ -171,6 +171,25 @@ def _is_power_of_2(n: int) -> bool:
     return n != 0 and (n & (n - 1)) == 0
 
 
+class _SplitLast(Function):
+    """x[..., :n], x[..., n:] as views; backward is ONE concatenation of the two gradients
+    (autograd's slice backward would zero-fill the full tensor twice and add)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = n, x.shape
+        return x[..., :n], x[..., n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros(*ctx.shape[:-1], ctx.n)
+        if gb is None:
+            gb = ref.new_zeros(*ctx.shape[:-1], ctx.shape[-1] - ctx.n)
+        return torch.cat([ga, gb], -1), None
+
+
 _INV_WH = {}
 
 
@@ -257,8 +276,9 @@ class MSDeformAttn(nn.Module):
             b = torch.cat([b_off, self.attention_weights.bias], 0)
             both = F.linear(query, w, b)
             n_off = self.sampling_offsets.out_features
-            offsets = both[..., :n_off].view(N, Len_q, H, self.n_levels, self.n_points, 2)
-            weights = both[..., n_off:].reshape(N, Len_q, H, self.n_levels * self.n_points)
+            off2, wts2 = _SplitLast.apply(both, n_off)
+            offsets = off2.view(N, Len_q, H, self.n_levels, self.n_points, 2)
+            weights = wts2.reshape(N, Len_q, H, self.n_levels * self.n_points)
         else:
             offsets = self.sampling_offsets(query).view(N, Len_q, H, self.n_levels, self.n_points, 2)
             weights = self.attention_weights(query).view(N, Len_q, H, self.n_levels * self.n_points)
