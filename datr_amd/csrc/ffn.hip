@@ -18,6 +18,9 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// RELU = true : dh <- dh * (h > 0) in place, column partial sums of the result
+// RELU = false: column partial sums of dh (read-only; `h` unused)
+template <bool RELU>
 __global__ __launch_bounds__(kThreads) void relu_bwd_bias_kernel(
     float4 *__restrict__ dh, const float4 *__restrict__ h, int64_t rows, int cols4,
     float4 *__restrict__ partial)
@@ -30,23 +33,29 @@ __global__ __launch_bounds__(kThreads) void relu_bwd_bias_kernel(
     // two rows in flight per thread: a wave covers 1 KiB of each row, fully coalesced
     for (; r + stride < rows; r += 2 * stride) {
         const int64_t i0 = r * cols4 + c, i1 = (r + stride) * cols4 + c;
-        const float4 g0 = dh[i0], a0 = h[i0], g1 = dh[i1], a1 = h[i1];
-        float4 z0, z1;
-        z0.x = a0.x > 0.f ? g0.x : 0.f; z0.y = a0.y > 0.f ? g0.y : 0.f;
-        z0.z = a0.z > 0.f ? g0.z : 0.f; z0.w = a0.w > 0.f ? g0.w : 0.f;
-        z1.x = a1.x > 0.f ? g1.x : 0.f; z1.y = a1.y > 0.f ? g1.y : 0.f;
-        z1.z = a1.z > 0.f ? g1.z : 0.f; z1.w = a1.w > 0.f ? g1.w : 0.f;
-        dh[i0] = z0; dh[i1] = z1;
+        const float4 g0 = dh[i0], g1 = dh[i1];
+        float4 z0 = g0, z1 = g1;
+        if (RELU) {
+            const float4 a0 = h[i0], a1 = h[i1];
+            z0.x = a0.x > 0.f ? g0.x : 0.f; z0.y = a0.y > 0.f ? g0.y : 0.f;
+            z0.z = a0.z > 0.f ? g0.z : 0.f; z0.w = a0.w > 0.f ? g0.w : 0.f;
+            z1.x = a1.x > 0.f ? g1.x : 0.f; z1.y = a1.y > 0.f ? g1.y : 0.f;
+            z1.z = a1.z > 0.f ? g1.z : 0.f; z1.w = a1.w > 0.f ? g1.w : 0.f;
+            dh[i0] = z0; dh[i1] = z1;
+        }
         s.x += z0.x; s.y += z0.y; s.z += z0.z; s.w += z0.w;
         s.x += z1.x; s.y += z1.y; s.z += z1.z; s.w += z1.w;
     }
     if (r < rows) {
         const int64_t i0 = r * cols4 + c;
-        const float4 g0 = dh[i0], a0 = h[i0];
-        float4 z0;
-        z0.x = a0.x > 0.f ? g0.x : 0.f; z0.y = a0.y > 0.f ? g0.y : 0.f;
-        z0.z = a0.z > 0.f ? g0.z : 0.f; z0.w = a0.w > 0.f ? g0.w : 0.f;
-        dh[i0] = z0;
+        const float4 g0 = dh[i0];
+        float4 z0 = g0;
+        if (RELU) {
+            const float4 a0 = h[i0];
+            z0.x = a0.x > 0.f ? g0.x : 0.f; z0.y = a0.y > 0.f ? g0.y : 0.f;
+            z0.z = a0.z > 0.f ? g0.z : 0.f; z0.w = a0.w > 0.f ? g0.w : 0.f;
+            dh[i0] = z0;
+        }
         s.x += z0.x; s.y += z0.y; s.z += z0.z; s.w += z0.w;
     }
     partial[(int64_t)blockIdx.y * cols4 + c] = s;
@@ -79,9 +88,10 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(
 
 extern "C" int64_t datr_relu_bwd_bias_partial_rows(int64_t rows) {
     // enough row-slices to fill the chip (2 column blocks x 512 = 1024 workgroups at cols 2048)
-    // without making the per-column finishing sum long
-    int64_t n = rows < 512 ? rows : 512;
-    return n < 1 ? 1 : n;
+    // without making the per-column finishing sum long; small inputs: ~32 rows per slice
+    int64_t n = rows / 32;
+    n = n < 1 ? 1 : (n > 512 ? 512 : n);
+    return n;
 }
 
 extern "C" int datr_relu_bwd_bias_f32(float *dh, const float *h, int64_t rows, int64_t cols,
@@ -97,11 +107,35 @@ extern "C" int datr_relu_bwd_bias_f32(float *dh, const float *h, int64_t rows, i
     const int cols4 = (int)(cols / 4);
     const int nblk = (int)datr_relu_bwd_bias_partial_rows(rows);
     dim3 grid((unsigned)((cols4 + kThreads - 1) / kThreads), (unsigned)nblk);
-    hipLaunchKernelGGL(relu_bwd_bias_kernel, grid, dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<true>, grid, dim3(kThreads), 0, st,
                        reinterpret_cast<float4 *>(dh), reinterpret_cast<const float4 *>(h), rows,
                        cols4, reinterpret_cast<float4 *>(partial));
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((cols4 + 7) / 8)), dim3(kThreads), 0, st,
                        reinterpret_cast<const float4 *>(partial), nblk, cols4,
                        reinterpret_cast<float4 *>(db));
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+// Column sums of a rows x cols fp32 matrix (the bias gradient of a linear layer), same two-stage
+// deterministic scheme; `partial` = datr_relu_bwd_bias_partial_rows(rows) * cols floats.
+extern "C" int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial,
+                               float *out, void *stream) {
+    if (rows < 0 || cols <= 0 || (cols & 3) || cols > (1 << 20)) return DATR_EINVAL;
+    if (!out) return DATR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0)
+        return hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), st) == hipSuccess ? DATR_OK
+                                                                                     : DATR_ELAUNCH;
+    if (!x || !partial) return DATR_EINVAL;
+    const int cols4 = (int)(cols / 4);
+    const int nblk = (int)datr_relu_bwd_bias_partial_rows(rows);
+    dim3 grid((unsigned)((cols4 + kThreads - 1) / kThreads), (unsigned)nblk);
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<false>, grid, dim3(kThreads), 0, st,
+                       reinterpret_cast<float4 *>(const_cast<float *>(x)),
+                       static_cast<const float4 *>(nullptr), rows, cols4,
+                       reinterpret_cast<float4 *>(partial));
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((cols4 + 7) / 8)), dim3(kThreads), 0, st,
+                       reinterpret_cast<const float4 *>(partial), nblk, cols4,
+                       reinterpret_cast<float4 *>(out));
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }

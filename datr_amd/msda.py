@@ -24,6 +24,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _native
+from .fused import FastLinear, linear as fast_linear
 
 __all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "MSDeformAttnFunction",
            "MSDeformAttn"]
@@ -225,10 +226,10 @@ class MSDeformAttn(nn.Module):
         self.im2col_step = 64
         self.d_model, self.n_levels = d_model, n_levels
         self.n_heads, self.n_points = n_heads, n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.output_proj = nn.Linear(d_model, d_model)
+        self.sampling_offsets = FastLinear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = FastLinear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = FastLinear(d_model, d_model)
+        self.output_proj = FastLinear(d_model, d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -274,7 +275,7 @@ class MSDeformAttn(nn.Module):
                 fold_wh = True
             w = torch.cat([w_off, self.attention_weights.weight], 0)
             b = torch.cat([b_off, self.attention_weights.bias], 0)
-            both = F.linear(query, w, b)
+            both = fast_linear(query, w, b)
             n_off = self.sampling_offsets.out_features
             off2, wts2 = _SplitLast.apply(both, n_off)
             offsets = off2.view(N, Len_q, H, self.n_levels, self.n_points, 2)

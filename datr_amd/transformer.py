@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from .fused import FastLinear
 from .msda import MSDeformAttn
 from .nested import inverse_sigmoid
 
@@ -31,7 +32,7 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
-        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(FastLinear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
@@ -390,7 +391,7 @@ class DeformableTransformer(nn.Module):
         self.two_stage_add_query_num = 0
         self.two_stage_learn_wh = two_stage_learn_wh
         if two_stage_type == "standard":
-            self.enc_output = nn.Linear(d_model, d_model)
+            self.enc_output = FastLinear(d_model, d_model)
             self.enc_output_norm = nn.LayerNorm(d_model)
             self.two_stage_wh_embedding = nn.Embedding(1, 2) if two_stage_learn_wh else None
         if two_stage_type == "no":

@@ -181,6 +181,10 @@ int datr_conv3x3_forward_f32(const float *x, const float *wt, const float *bias,
 int64_t datr_relu_bwd_bias_partial_rows(int64_t rows);
 int datr_relu_bwd_bias_f32(float *dh, const float *h, int64_t rows, int64_t cols, float *partial,
                            float *db, void *stream);
+/* Column sums out[c] = sum_r x[r, c] -- the bias gradient of any linear layer (autograd's
+ * `grad_output.sum(0)`), same deterministic two-stage scheme and scratch size. */
+int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial, float *out,
+                    void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hungarian matching on the device: all of a step's rectangular assignment problems in one

@@ -141,3 +141,27 @@ def test_add_layer_norm_matches_autograd(shape):
     x.grad = r.grad = norm.weight.grad = norm.bias.grad = None
     add_layer_norm(x, r, norm).backward(go)
     assert torch.equal(norm.weight.grad, got[3]) and torch.equal(norm.bias.grad, got[4])
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(4400, 256, 256), (88892, 256, 384), (7, 32, 4), (300, 64, 128)])
+def test_fast_linear_matches_autograd(rows, cin, cout):
+    """FastLinear: same GEMMs as nn.Linear, bias gradient from the column-sum kernel."""
+    from datr_amd.fused import FastLinear
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows)
+    lin = FastLinear(cin, cout).to(dev)
+    x = torch.randn(2, rows, cin, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(2, rows, cout, generator=g).to(dev)
+    y = lin(x)
+    y.backward(go)
+    got = [y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    yr = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    yr.backward(go)
+    ref = [yr.detach(), x.grad, lin.weight.grad, lin.bias.grad]
+    for a, b in zip(got[:3], ref[:3]):
+        assert torch.equal(a, b)                                     # the same GEMM calls
+    scale = max(float(ref[3].abs().max()), 1e-6)
+    assert float((got[3] - ref[3]).abs().max()) <= 2e-5 * scale
+    with torch.no_grad():
+        assert torch.equal(lin(x), yr.detach())
