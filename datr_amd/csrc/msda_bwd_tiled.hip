@@ -38,7 +38,7 @@
 #include "datr_hip.h"
 #include "msda_tiled.h"
 
-#ifdef DATR_PROBE
+#if defined(DATR_PROBE) && !defined(DATR_PROBE_NOTICKS)
 __device__ unsigned long long datr_phase_cycles[8];
 #define DATR_TICK(i)                                                                   \
     do {                                                                               \
