@@ -151,6 +151,61 @@ class MsdaTimer:
                 "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
 
 
+def teacher_student_stage(args, device):
+    """BASELINE config 5 on one GPU: datr_amd.engine.train_one_epoch_with_self_training (the
+    reference's epoch function, engine.py:146-342) on synthetic batches -- EMA teacher forward
+    on the target images, pseudo labels (threshold + class-wise NMS), student step on source +
+    strongly augmented target, EMA update of the teacher.  Reference semantics kept: one
+    `.item()` per step for the logged loss."""
+    from datr_amd import tuning
+    from datr_amd.config import c2f_args, get_param_dict
+    from datr_amd.detector import build_dino
+    from datr_amd.ema import ModelEMA
+    from datr_amd.engine import train_one_epoch_with_self_training
+    from datr_amd.nested import NestedTensor
+    tuning.enable()
+    cfg = c2f_args(device=str(device))
+    # random-initialised weights score every box ~0.01-0.05: the C2F threshold (0.3) would leave
+    # the target branch idle, so the synthetic run keeps boxes above 0.02 (stated in the line)
+    cfg.pseudo_label_threshold = 0.02
+    torch.manual_seed(0)
+    model, criterion, _ = build_dino(cfg)
+    model.to(device)
+    model.backbone.to(memory_format=torch.channels_last)
+    teacher = ModelEMA(model, decay=cfg.ema_decay_teacher)
+    optimizer = torch.optim.AdamW(get_param_dict(cfg, model), lr=cfg.lr, weight_decay=cfg.weight_decay,
+                                  fused=True)
+    samples, targets = synthetic_batch(args.batch, args.height, args.width, args.num_gt, device, seed=1)
+    samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(7)
+    strong = NestedTensor((samples.tensors + 0.3 * torch.randn(samples.tensors.shape, generator=g).to(device))
+                          .contiguous(memory_format=torch.channels_last), samples.mask, padded=False)
+    meta = [{"image_id": torch.tensor([i]), "orig_size": torch.tensor([args.height, args.width]),
+             "size": torch.tensor([args.height, args.width])} for i in range(args.batch)]
+    batch = (samples, tuple(targets), tuple(meta), strong)
+
+    def run(n):
+        stats = train_one_epoch_with_self_training(model, teacher, criterion, [batch] * n, [batch] * n,
+                                                   optimizer, device, 0, cfg.clip_max_norm, args=cfg)
+        teacher.update(model)
+        return stats
+    run(args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "images/sec, teacher-student mutual-learning step (EMA teacher + student), bs=2/GPU, 1333x800",
+        "value": round(2 * args.batch * args.steps / dt, 3), "unit": "images/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 5 on one GPU: teacher forward + pseudo labels + student "
+                               "step incl. target-domain criterion", "pseudo_label_threshold": 0.02,
+                   "pseudo_labelled_images_per_step": stats.get("num_pseudo_images")}}), flush=True)
+
+
 def mfma_utilisation(device, rows):
     """MFMA utilisation of the linears the step spends most of its GEMM time in -- the encoder
     FFN, [rows, 256] x [256, 2048] and back (54 % of forward FLOPs) -- timed with HIP
@@ -245,7 +300,14 @@ def main():
                          "MIOpen's measured-fastest fp32 solvers want; same arithmetic)")
     ap.add_argument("--no-tuned-gemm", dest="tuned_gemm", action="store_false",
                     help="leave hipBLASLt on its default heuristic (datr_amd/tuning)")
+    ap.add_argument("--stage", choices=["burn-in", "teacher"], default="burn-in",
+                    help="teacher: the teacher-student stage (BASELINE config 5) on one GPU; "
+                         "the default is the headline burn-in step")
     args = ap.parse_args()
+    if args.stage == "teacher":
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(device)
+        return teacher_student_stage(args, device)
 
     from datr_amd.dist import init_distributed
     rank, local_rank, world = init_distributed()
