@@ -158,6 +158,9 @@ class SetCriterion(nn.Module):
 
     # ---- domain-adaptation losses -----------------------------------------------------------
     def loss_da(self, outputs):
+        ready = getattr(outputs, "_ready_event", None)
+        if ready is not None:       # produced on a side stream (detector.py, overlap_d_img)
+            torch.cuda.current_stream().wait_event(ready)
         B = outputs.shape[0]
         assert B % 2 == 0
         src, tgt = outputs[:B // 2], outputs[B // 2:]

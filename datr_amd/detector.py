@@ -38,6 +38,19 @@ from .registry import MODULE_BUILD_FUNCS
 from .transformer import MLP, build_deformable_transformer
 
 
+OVERLAP_D_IMG = __import__("os").environ.get("DATR_OVERLAP_D_IMG", "1") != "0"     # A/B switch
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        from .dist import EXTRA_STREAMS
+        EXTRA_STREAMS.append(_SIDE_STREAMS[key])
+    return _SIDE_STREAMS[key]
+
+
 class DINO(nn.Module):
     def __init__(self, backbone, transformer, num_classes, num_queries, aux_loss=False,
                  iter_update=False, query_dim=2, random_refpoints_xy=False, fix_refpoints_hw=-1,
@@ -198,6 +211,14 @@ class DINO(nn.Module):
             input_query_bbox = input_query_label = attn_mask = dn_meta = None
 
         merged = da and self.merge_encoder_passes
+        # The image-level discriminator only needs the projected backbone features.  On the device
+        # it runs on a SIDE STREAM that starts when the main stream reaches the decoder, so its
+        # dense convolutions fill the gaps between the decoder's thousands of tiny kernels
+        # (forward here; autograd replays the same stream assignment in backward, where D_img's
+        # nodes -- created after the decoder's -- are scheduled right before the decoder's).
+        overlap_d_img = da and OVERLAP_D_IMG and srcs_all[0].is_cuda
+        if overlap_d_img:
+            decoder_start = torch.cuda.Event()
         if merged:
             # the encoder is per-sample: run it ONCE on all 2B images (the reference runs it
             # separately for the source and the target half, dino.py:291,380 -- same values,
@@ -206,6 +227,8 @@ class DINO(nn.Module):
             half = srcs_all[0].shape[0] // 2
             enc_src = self.transformer.slice_encoded(enc_all, slice(0, half))
             enc_tgt = self.transformer.slice_encoded(enc_all, slice(half, None))
+            if overlap_d_img:
+                decoder_start.record()
             if self.merge_decoder_passes:
                 # ONE decoder pass for all 2B images as well.  The target images get the source's
                 # de-noising slots as placeholders: the attention mask already forbids matching
@@ -234,6 +257,8 @@ class DINO(nn.Module):
                 hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer.decode(
                     enc_src, input_query_bbox, input_query_label, attn_mask)
         else:
+            if overlap_d_img:
+                decoder_start.record()
             hs, reference, hs_enc, ref_enc, init_box_proposal = self.transformer(
                 srcs, masks, input_query_bbox, poss, input_query_label, attn_mask)
         hs[0] = hs[0] + self.label_enc.weight[0, 0] * 0.0
@@ -256,8 +281,24 @@ class DINO(nn.Module):
         if da:
             da_output = {}
             # 1. image-level alignment: per-pixel domain logits on every level, all 2B images
-            d_out = [self.D_img(grad_reverse(src)) for src in srcs_all]
-            da_output["backbone_DA"] = torch.cat([o.flatten(2).transpose(1, 2) for o in d_out], dim=1)
+            if overlap_d_img:
+                main = torch.cuda.current_stream()
+                side = _side_stream(srcs_all[0].device)
+                side.wait_event(decoder_start)
+                with torch.cuda.stream(side):
+                    for src in srcs_all:
+                        src.record_stream(side)
+                    d_out = [self.D_img(grad_reverse(src)) for src in srcs_all]
+                    backbone_da = torch.cat([o.flatten(2).transpose(1, 2) for o in d_out], dim=1)
+                    backbone_da.record_stream(main)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                # consumers (SetCriterion.loss_da) make their stream wait for this event
+                backbone_da._ready_event = done
+                da_output["backbone_DA"] = backbone_da
+            else:
+                d_out = [self.D_img(grad_reverse(src)) for src in srcs_all]
+                da_output["backbone_DA"] = torch.cat([o.flatten(2).transpose(1, 2) for o in d_out], dim=1)
 
             # 2. class-wise query prototypes, source domain
             pad = dn_meta["pad_size"] if dn_meta is not None else 0

@@ -32,6 +32,11 @@ import torch.distributed as dist
 from torch import nn
 
 
+# streams other than the default one on which some gradient may be produced (registered by the
+# code that creates them); see GradAllReducer._launch
+EXTRA_STREAMS = []
+
+
 class _Bucket:
     def view(self, p: nn.Parameter, offset: int) -> torch.Tensor:
         """The slice of the flat buffer that is `p`'s gradient, with `p`'s own strides: a
@@ -109,6 +114,14 @@ class GradAllReducer:
     def _launch(self, b: _Bucket):
         b.launched = True
         if self.world > 1:
+            if b.flat.is_cuda:
+                # Gradients of one bucket may have been written on different streams (the model runs
+                # its image-level discriminator on a side stream, detector.py): the collective is
+                # ordered after the CURRENT stream only, so make that stream wait for the others.
+                cur = torch.cuda.current_stream(b.flat.device)
+                for s in [torch.cuda.default_stream(b.flat.device)] + list(EXTRA_STREAMS):
+                    if s != cur and s.device == b.flat.device:
+                        cur.wait_stream(s)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- step API -------------------------------------------------------------------------------
