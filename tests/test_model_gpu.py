@@ -132,3 +132,44 @@ def test_teacher_student_step_runs_on_gpu():
     n_ref = len(g["pseudo_labels"])
     assert abs(len(last["pseudo_targets"][0]["labels"]) - n_ref) <= max(2, n_ref // 5)
     assert abs(stats["loss"] - float(g["stat_values"][list(g["stat_keys"]).index("loss")])) < 0.05 * stats["loss"]
+
+
+def test_training_step_has_no_host_synchronisation():
+    """forward + SetCriterion + backward + clip + AdamW on the device must not block the host:
+    the matcher runs on the device (csrc/lsap.hip), index tensors are cached, CDN uses no
+    data-dependent shapes.  torch's sync-debug mode raises on any synchronising call."""
+    from datr_amd.config import get_param_dict
+    from datr_amd.criterion import weighted_total
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    dev = torch.device("cuda:0")
+    args, model, criterion, _ = build_model()
+    model.to(dev).train()
+    criterion.to(dev).train()
+    g = torch.Generator().manual_seed(11)
+    imgs = [torch.randn(3, 224, 288, generator=g).to(dev) for _ in range(4)]      # 2 source + 2 target
+    samples = nested_tensor_from_tensor_list(imgs)
+    targets = []
+    for n in (3, 5):
+        cxcy = torch.rand(n, 2, generator=g) * 0.5 + 0.25
+        wh = torch.rand(n, 2, generator=g) * 0.2 + 0.05
+        targets.append({"boxes": torch.cat([cxcy, wh], 1).to(dev),
+                        "labels": torch.randint(1, 9, (n,), generator=g).to(dev)})
+    opt = torch.optim.AdamW(get_param_dict(args, model), lr=1e-4, weight_decay=1e-4, fused=True)
+
+    def step():
+        loss_dict = criterion(model(samples, targets), targets)
+        loss = weighted_total(loss_dict, criterion.weight_dict)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        opt.step()
+        return loss
+    for _ in range(2):                      # warm-up: caches, MIOpen / hipBLASLt handles
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss = step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(loss)
