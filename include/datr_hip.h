@@ -225,6 +225,19 @@ int datr_add_layernorm_backward_f32(const float *dy, const float *x, const float
                                     int64_t rows, int64_t C, float *dx, float *partial, float *dgamma,
                                     float *dbeta, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline tail on the device: ToTensor + Normalize + pad into the batch + padding mask
+ * for ONE image (/root/reference/datasets/da_transforms.py:250-276, util/misc.py:387-409).
+ *   img   uint8 [H, W, 3] (HWC, device)      mean, std  3 host floats each
+ *   out   this image's slot of the float batch: [3, Hp, Wp] (channels_last = 0) or [Hp, Wp, 3]
+ *   mask  this image's [Hp, Wp] slot of the bool mask (1 = padding)
+ * Every element of both slots is written (padding = 0 / 1).  Bit-exact with the reference's
+ * fp32 operation sequence (x / 255 - mean) / std.
+ * ------------------------------------------------------------------------------------------ */
+int datr_normalize_pad_u8_f32(const uint8_t *img, int64_t H, int64_t W, const float *mean,
+                              const float *std, int64_t Hp, int64_t Wp, int channels_last, float *out,
+                              uint8_t *mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
