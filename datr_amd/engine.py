@@ -135,20 +135,28 @@ def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loa
         target_labels = [{k: v.to(device) for k, v in t.items()} for t in target_labels]
         unit = torch.ones(len(target_labels), 2, dtype=torch.long, device=device)
         results = post(teacher_out, unit, not_to_xyxy=True)
+
+        with torch.autocast(device_type=device.type, enabled=amp):
+            # The student forward and the source-domain criterion do not depend on the pseudo
+            # labels: they are ENQUEUED before the pseudo-label selection below, whose
+            # data-dependent sizes force host synchronisations (threshold, NMS) -- the GPU then
+            # works through the student forward while the host waits, instead of idling after
+            # the teacher forward (the reference selects first, engine.py:213-226; same values).
+            if need_tgt_for_training:
+                outputs = model(samples_strong_aug, source_labels, self_training_flag=True)
+            else:
+                outputs = model(samples_strong_aug, self_training_flag=True)
+            source_outputs, target_outputs = spilt_output(outputs)
+            weight_dict = criterion.weight_dict
+            loss_dict_source = criterion(source_outputs, source_labels, target_domain_flag=False)
+
         threshold = np.asarray([args.pseudo_label_threshold] * args.num_classes)
         idx_list, labels_d, boxes_d, scores_d = get_pseudo_label_via_threshold(results, threshold=threshold)
         pseudo = deal_pesudo_label(target_labels, idx_list, labels_d, boxes_d, scores_d)
         pseudo = rescale_pseudo_targets(unlabel_img, pseudo)
 
         with torch.autocast(device_type=device.type, enabled=amp):
-            if need_tgt_for_training:
-                outputs = model(samples_strong_aug, source_labels, self_training_flag=True)
-            else:
-                outputs = model(samples_strong_aug, self_training_flag=True)
-            source_outputs, target_outputs = spilt_output(outputs)
             valid_target_outputs, pseudo_list = get_valid_output(target_outputs, pseudo, idx_list)
-            weight_dict = criterion.weight_dict
-            loss_dict_source = criterion(source_outputs, source_labels, target_domain_flag=False)
             loss_dict_target = criterion(valid_target_outputs, pseudo_list, target_domain_flag=True)
             losses_source = weighted_total(loss_dict_source, weight_dict)
             losses_target = weighted_total(loss_dict_target, weight_dict)
