@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--per-step", type=int, default=24, help="marker launches per step")
     ap.add_argument("--out", default=None)
     ap.add_argument("--top", type=int, default=70)
+    ap.add_argument("--split", default=None,
+                    help="also print this kernel's launches grouped by grid size (e.g. msda_fwd_rows: "
+                         "encoder and decoder calls share a kernel name)")
+    ap.add_argument("--split-out", default=None)
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     ks, ke, kn = "Start_Timestamp", "End_Timestamp", "Kernel_Name"
@@ -70,6 +74,19 @@ def main():
           f"launches_per_step={len(window) / a.steps:.0f} distinct={len(agg)}")
     for row in out[:a.top + 1]:
         print(", ".join(row))
+    if a.split:
+        groups = defaultdict(list)
+        gk = next((k for k in ("Grid_Size", "Grid_Size_X", "grid_size") if k in window[0]), None)
+        for r in window:
+            if a.split in r[kn]:
+                groups[r[gk] if gk else "?"].append((int(r[ke]) - int(r[ks])) / 1e3)
+        lines = [f"# {a.split}: launches in the steady-state window grouped by grid size ({gk})",
+                 "grid_size,launches_per_step,avg_us,min_us,max_us"]
+        for g, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            lines.append(f"{g},{len(v) / a.steps:.1f},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}")
+        print("\n".join(lines))
+        if a.split_out:
+            open(a.split_out, "w").write("\n".join(lines) + "\n")
     if a.out:
         with open(a.out, "w") as f:
             f.write(f"# gpu_busy_ms_per_step={busy / a.steps / 1e6:.1f}\n")
