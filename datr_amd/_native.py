@@ -38,6 +38,8 @@ _SIGNATURES = {
     "datr_normalize_pad_u8_f32": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
     "datr_lsap_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "datr_colsum_f32": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "datr_conv3x3_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
+                                      ctypes.c_float, _vp, _vp],
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_focal_loss_forward_f32": [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
                                     _vp, _vp, _vp],

@@ -261,3 +261,25 @@ class FastLinear(torch.nn.Linear):
 
     def forward(self, x):
         return linear(x, self.weight, self.bias)
+
+
+def conv3x3_lrelu_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None,
+                       slope: float = 1.0, out_scale: float = 1.0) -> torch.Tensor:
+    """conv3x3_lrelu for torch.channels_last tensors (csrc/conv3x3_nhwc.hip: the input patch of a
+    channel chunk is staged in LDS once for all nine taps).  Forward only; Cin % 16 == 0,
+    Cout % 128 == 0.  Returns a channels_last tensor."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    assert weight.shape == (Cout, Cin, 3, 3)
+    x = x.contiguous(memory_format=torch.channels_last)
+    wt = weight.permute(2, 3, 1, 0).contiguous()
+    y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32,
+                    memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _native.lib.datr_conv3x3_nhwc_forward_f32(
+            x.data_ptr(), wt.data_ptr(), 0 if bias is None else bias.contiguous().data_ptr(),
+            N, H, W, Cin, Cout, float(slope), float(out_scale), y.data_ptr(),
+            _native.current_stream_ptr(x.device))
+    _native.check(rc, "conv3x3_nhwc_forward")
+    return y

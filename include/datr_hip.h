@@ -168,6 +168,14 @@ int datr_conv3x3_forward_f32(const float *x, const float *wt, const float *bias,
                              int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                              float slope, float out_scale, float *y, void *stream);
 
+/* Same convolution on NHWC (torch.channels_last) tensors, the layout the backbone runs in:
+ *   x [N, H, W, Cin]   wt [3, 3, Cin, Cout] = W.permute(2, 3, 1, 0)   y [N, H, W, Cout]
+ * Cin % 16 == 0, Cout % 128 == 0.  The input patch of a channel chunk is staged in LDS once and
+ * re-used by all nine taps (csrc/conv3x3_nhwc.hip). */
+int datr_conv3x3_nhwc_forward_f32(const float *x, const float *wt, const float *bias, int64_t N,
+                                  int64_t H, int64_t W, int64_t Cin, int64_t Cout, float slope,
+                                  float out_scale, float *y, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * FFN backward, the non-GEMM pass: given h = relu(linear1(x)) saved by the forward and
  * dh = d loss / d h, computes IN PLACE dh <- dh * (h > 0) and db[c] = sum_r dh[r, c]

@@ -165,3 +165,26 @@ def test_fast_linear_matches_autograd(rows, cin, cout):
     assert float((got[3] - ref[3]).abs().max()) <= 2e-5 * scale
     with torch.no_grad():
         assert torch.equal(lin(x), yr.detach())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 13, 21, 128), (1, 256, 25, 42, 128), (3, 16, 7, 5, 256),
+                                   (2, 128, 50, 84, 128)])
+@pytest.mark.parametrize("slope", [0.2, 1.0])
+def test_conv3x3_lrelu_nhwc(shape, slope):
+    """NHWC MFMA conv3x3 (+bias +LeakyReLU) vs conv2d + leaky_relu
+    (/root/reference/models/dino/DA_utils.py:69-79); ragged tiles, several channel chunks."""
+    import torch.nn.functional as F
+    from datr_amd.fused import conv3x3_lrelu_nhwc
+    N, Cin, H, W, Cout = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), slope)
+    out = conv3x3_lrelu_nhwc(x, w, b, slope=slope)
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    assert (out.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    neg = conv3x3_lrelu_nhwc(x, w, None, slope=slope, out_scale=-1.0)
+    ref2 = -F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=1), slope)
+    assert (neg.double() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
