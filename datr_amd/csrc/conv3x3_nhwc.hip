@@ -48,8 +48,8 @@ __global__ __launch_bounds__(kThreads) void conv3x3_nhwc_mfma(
     float *__restrict__ Y, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, float slope,
     float out_scale)
 {
-    __shared__ __attribute__((aligned(16))) float patch[2][PH * PW * PSTR];     // 2 x 14.4 KB
-    __shared__ __attribute__((aligned(16))) float wsl[2][CK][BN];               // 2 x 8 KB
+    __shared__ __attribute__((aligned(16))) float patch[PH * PW * PSTR];        // 14.4 KB
+    __shared__ __attribute__((aligned(16))) float wsl[2][CK][BN];               // 16 KB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -70,48 +70,34 @@ __global__ __launch_bounds__(kThreads) void conv3x3_nhwc_mfma(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
-    // Global -> register -> LDS staging, TWO steps ahead for the weight slabs (an L2 round trip
-    // under load is longer than the 32 MFMAs of one tap) and one tap ahead for the input patch.
-    // A step = (channel chunk, tap); slab of step s: element f = tid + 256 u of [CK][BN].
-    float4 wreg[2][2];
-    auto load_w = [&](int step, float4 (&dst)[2]) {
-        const int ch = step / 9, tap = step - ch * 9;
+    // this thread's two float4 of a weight slab [CK][BN]: element f = tid + 256 * u
+    float4 wreg[2];
+    auto load_w = [&](int tap, int ci0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int f = tid + kThreads * u;              // float4 index 0..511
-            dst[u] = *reinterpret_cast<const float4 *>(
-                Wt + ((size_t)tap * Cin + ch * CK + (f >> 5)) * Cout + co0 + (f & 31) * 4);
+            const int k = f >> 5, c4 = f & 31;
+            wreg[u] = *reinterpret_cast<const float4 *>(
+                Wt + ((size_t)tap * Cin + ci0 + k) * Cout + co0 + c4 * 4);
         }
     };
-    auto store_w = [&](int buf, const float4 (&src)[2]) {
+    auto store_w = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int f = tid + kThreads * u;
-            *reinterpret_cast<float4 *>(&wsl[buf][f >> 5][(f & 31) * 4]) = src[u];
+            *reinterpret_cast<float4 *>(&wsl[buf][f >> 5][(f & 31) * 4]) = wreg[u];
         }
     };
-    // patch: PH * PW pixels x 4 float4 (16 channels) = 720 float4 = 3 per thread (last partial)
-    float4 preg[3];
+    // patch staging: PH * PW pixels x 4 float4 (16 channels) = 720 float4
     auto load_patch = [&](int ci0) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int f = tid + kThreads * u;
-            preg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < PH * PW * 4) {
-                const int pix = f >> 2, q = f & 3;
-                const int py = pix / PW, px = pix - py * PW;
-                const int yy = y0 + py - 1, xx = x0 + px - 1;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                    preg[u] = *reinterpret_cast<const float4 *>(Xn + ((size_t)yy * W + xx) * Cin + ci0 + q * 4);
-            }
-        }
-    };
-    auto store_patch = [&](int pb) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int f = tid + kThreads * u;
-            if (f < PH * PW * 4)
-                *reinterpret_cast<float4 *>(&patch[pb][(f >> 2) * PSTR + (f & 3) * 4]) = preg[u];
+        for (int f = tid; f < PH * PW * 4; f += kThreads) {
+            const int pix = f >> 2, q = f & 3;
+            const int py = pix / PW, px = pix - py * PW;
+            const int yy = y0 + py - 1, xx = x0 + px - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v = *reinterpret_cast<const float4 *>(Xn + ((size_t)yy * W + xx) * Cin + ci0 + q * 4);
+            *reinterpret_cast<float4 *>(&patch[pix * PSTR + q * 4]) = v;
         }
     };
 
@@ -124,54 +110,43 @@ __global__ __launch_bounds__(kThreads) void conv3x3_nhwc_mfma(
         abase[i] = (py * PW + px) * PSTR + lhi * 4;
     }
 
-    const int nchunks = Cin / CK, nsteps = nchunks * 9;
-    load_patch(0);
-    load_w(0, wreg[0]);
-    store_patch(0);
-    store_w(0, wreg[0]);
-    if (nsteps > 1) load_w(1, wreg[1]);
-    __syncthreads();
-#pragma unroll 1
+    const int nchunks = Cin / CK;
+    load_w(0, 0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        const float *pt = patch[ch & 1];
-#pragma unroll
+        const int ci0 = ch * CK;
+        __syncthreads();                        // previous chunk's readers are done with the patch
+        load_patch(ci0);
+        store_w(0);
+        __syncthreads();
+#pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            const int step = ch * 9 + tap, buf = tap & 1;            // 9 odd: use the step parity below
-            const int sb = step & 1;
-            (void)buf;
-            if (step + 2 < nsteps) load_w(step + 2, wreg[sb]);      // slab s was stored a step ago
-            if (tap == 7 && ch + 1 < nchunks) load_patch((ch + 1) * CK);
+            const int buf = tap & 1;
+            // prefetch the next slab (next tap, or tap 0 of the next chunk)
+            const bool more = tap < 8 || ch + 1 < nchunks;
+            if (more) load_w(tap < 8 ? tap + 1 : 0, tap < 8 ? ci0 : ci0 + CK);
             const int r = tap / 3, s = tap - r * 3;
             const int toff = (r * PW + s) * PSTR;
-            float4 a[2][2];
-            float bw[2][4][2];
 #pragma unroll
             for (int grp = 0; grp < 2; ++grp) {          // two 8-channel groups of the chunk
+                float4 a[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    a[grp][i] = *reinterpret_cast<const float4 *>(&pt[abase[i] + toff + grp * 8]);
+                    a[i] = *reinterpret_cast<const float4 *>(&patch[abase[i] + toff + grp * 8]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int k = grp * 8 + lhi * 4 + t;
-                    bw[grp][t][0] = wsl[sb][k][wn * 64 + l31];
-                    bw[grp][t][1] = wsl[sb][k][wn * 64 + 32 + l31];
+                    const float b0 = wsl[buf][k][wn * 64 + l31];
+                    const float b1 = wsl[buf][k][wn * 64 + 32 + l31];
+                    const float a0 = t == 0 ? a[0].x : t == 1 ? a[0].y : t == 2 ? a[0].z : a[0].w;
+                    const float a1 = t == 0 ? a[1].x : t == 1 ? a[1].y : t == 2 ? a[1].z : a[1].w;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int grp = 0; grp < 2; ++grp) {
-                const float av0[4] = {a[grp][0].x, a[grp][0].y, a[grp][0].z, a[grp][0].w};
-                const float av1[4] = {a[grp][1].x, a[grp][1].y, a[grp][1].z, a[grp][1].w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bw[grp][t][0], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bw[grp][t][1], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bw[grp][t][0], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bw[grp][t][1], acc[1][1], 0, 0, 0);
-                }
-            }
-            if (step + 1 < nsteps) {
-                store_w(sb ^ 1, wreg[sb ^ 1]);          // slab s + 1, loaded during step s - 1
-                if (tap == 8) store_patch((ch + 1) & 1); // next chunk's patch, other buffer
+            if (more && tap < 8) {
+                store_w(buf ^ 1);               // the other buffer: its readers finished a tap ago
                 __syncthreads();
             }
         }
