@@ -13,8 +13,9 @@
 //   * K runs over input-channel chunks of 16 and, inside a chunk, over the 9 filter taps.  The
 //     INPUT PATCH of a chunk (10 x 18 pixels x 16 channels, halo included, zero outside the
 //     image) is staged in LDS ONCE and re-used by all 9 taps -- 9x fewer activation loads than an
-//     im2col-style K loop; only the 16 x 128 weight slab changes per tap (8 KB, two float4 per
-//     thread, register-prefetched while the previous tap is multiplied);
+//     im2col-style K loop; only the 16 x 128 weight slab changes per tap (8 KB, brought in by
+//     LDS-DMA -- `global_load_lds_dwordx4`, two instructions per wave, no staging registers --
+//     while the previous tap is multiplied);
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak).  The K pairing is chosen for the LDS: a
 //     lane fetches FOUR consecutive channels of its pixel with one ds_read_b128 (lanes 0-31:
 //     channels 0-3 of an 8-channel group, lanes 32-63: channels 4-7), and MFMA step t multiplies
@@ -70,22 +71,16 @@ __global__ __launch_bounds__(kThreads) void conv3x3_nhwc_mfma(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
-    // this thread's two float4 of a weight slab [CK][BN]: element f = tid + 256 * u
-    float4 wreg[2];
-    auto load_w = [&](int tap, int ci0) {
+    // weight slab [CK][BN] of (tap, chunk): 16 rows of 512 contiguous bytes -> LDS by LDS-DMA
+    // (1 KiB = two rows per wave instruction, two instructions per wave): no staging registers
+    auto dma_w = [&](int tap, int ci0, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int f = tid + kThreads * u;              // float4 index 0..511
-            const int k = f >> 5, c4 = f & 31;
-            wreg[u] = *reinterpret_cast<const float4 *>(
-                Wt + ((size_t)tap * Cin + ci0 + k) * Cout + co0 + c4 * 4);
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int f = tid + kThreads * u;
-            *reinterpret_cast<float4 *>(&wsl[buf][f >> 5][(f & 31) * 4]) = wreg[u];
+            const int row = (wave * 2 + u) * 2 + (lane >> 5);            // 0..15
+            const float *src = Wt + ((size_t)tap * Cin + ci0 + row) * Cout + co0 + (lane & 31) * 4;
+            __builtin_amdgcn_global_load_lds(
+                (__attribute__((address_space(1))) const void *)src,
+                (__attribute__((address_space(3))) void *)&wsl[buf][(wave * 2 + u) * 2][0], 16, 0, 0);
         }
     };
     // patch staging: PH * PW pixels x 4 float4 (16 channels) = 720 float4
@@ -111,19 +106,19 @@ __global__ __launch_bounds__(kThreads) void conv3x3_nhwc_mfma(
     }
 
     const int nchunks = Cin / CK;
-    load_w(0, 0);
+    dma_w(0, 0, 0);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int ci0 = ch * CK;
         __syncthreads();                        // previous chunk's readers are done with the patch
         load_patch(ci0);
-        store_w(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            const int buf = tap & 1;
-            // prefetch the next slab (next tap, or tap 0 of the next chunk)
+            // 9 taps per chunk: the slab buffer parity follows the global step count
+            const int buf = (ch * 9 + tap) & 1;
             const bool more = tap < 8 || ch + 1 < nchunks;
-            if (more) load_w(tap < 8 ? tap + 1 : 0, tap < 8 ? ci0 : ci0 + CK);
+            if (more) dma_w(tap < 8 ? tap + 1 : 0, tap < 8 ? ci0 : ci0 + CK, buf ^ 1);
             const int r = tap / 3, s = tap - r * 3;
             const int toff = (r * PW + s) * PSTR;
 #pragma unroll
@@ -146,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_nhwc_mfma(
                 }
             }
             if (more && tap < 8) {
-                store_w(buf ^ 1);               // the other buffer: its readers finished a tap ago
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next slab landed (this wave's part)
                 __syncthreads();
             }
         }
