@@ -37,6 +37,7 @@ def check(C, sizes):
     (300, [299, 5], 1),            # almost square (T == nq is SciPy's untransposed case: host path)
     (1024, [64], 3),
     (17, [3, 16], 2),
+    (900, [300, 150, 1], 1),       # many boxes: long augmenting paths, rows read from global memory
 ])
 def test_random_costs(nq, sizes, G):
     g = torch.Generator().manual_seed(nq + sum(sizes))

@@ -134,7 +134,8 @@ def test_teacher_student_step_runs_on_gpu():
     assert abs(stats["loss"] - float(g["stat_values"][list(g["stat_keys"]).index("loss")])) < 0.05 * stats["loss"]
 
 
-def test_training_step_has_no_host_synchronisation():
+@pytest.mark.parametrize("padded", [False, True])
+def test_training_step_has_no_host_synchronisation(padded):
     """forward + SetCriterion + backward + clip + AdamW on the device must not block the host:
     the matcher runs on the device (csrc/lsap.hip), index tensors are cached, CDN uses no
     data-dependent shapes.  torch's sync-debug mode raises on any synchronising call."""
@@ -146,8 +147,10 @@ def test_training_step_has_no_host_synchronisation():
     model.to(dev).train()
     criterion.to(dev).train()
     g = torch.Generator().manual_seed(11)
-    imgs = [torch.randn(3, 224, 288, generator=g).to(dev) for _ in range(4)]      # 2 source + 2 target
+    sizes = [(224, 288), (200, 288), (224, 250), (224, 288)] if padded else [(224, 288)] * 4
+    imgs = [torch.randn(3, h, w, generator=g).to(dev) for h, w in sizes]          # 2 source + 2 target
     samples = nested_tensor_from_tensor_list(imgs)
+    assert samples.padded is padded
     targets = []
     for n in (3, 5):
         cxcy = torch.rand(n, 2, generator=g) * 0.5 + 0.25
