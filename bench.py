@@ -316,7 +316,8 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    trainer = Trainer(args, device, distributed=world > 1)
+    from datr_amd.dist import FORCE_COLLECTIVES
+    trainer = Trainer(args, device, distributed=world > 1 or FORCE_COLLECTIVES)
     samples, targets = synthetic_batch(args.batch, args.height, args.width, args.num_gt, device,
                                        seed=1 + rank)
     if args.channels_last:
@@ -368,6 +369,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -325,7 +325,9 @@ class SetCriterion(nn.Module):
             indices, num_boxes = None, 1.0
 
         if is_dist_avail_and_initialized():
-            nb = torch.as_tensor([num_boxes], dtype=torch.float, device=device)
+            # torch.full = a fill kernel with a scalar argument; as_tensor([x], device=...) would be a
+            # pageable host->device copy, i.e. a host synchronisation in every step
+            nb = torch.full((1,), num_boxes, dtype=torch.float, device=device)
             dist.all_reduce(nb)
             if indices is None:
                 nb = nb - 1

@@ -35,6 +35,20 @@ from torch import nn
 # streams other than the default one on which some gradient may be produced (registered by the
 # code that creates them); see GradAllReducer._launch
 EXTRA_STREAMS = []
+# DATR_DIST_FORCE_COLLECTIVES=1: initialise the process group and issue every collective even at
+# world size 1 -- lets a 1-GPU box exercise the real RCCL code path (async all-reduce from autograd
+# hooks, stream ordering); values are unchanged (sum over one rank, divided by 1)
+FORCE_COLLECTIVES = __import__("os").environ.get("DATR_DIST_FORCE_COLLECTIVES", "0") == "1"
+
+
+_LAUNCH_STREAMS = {}
+
+
+def _launch_stream(device):
+    key = (device.type, device.index)
+    if key not in _LAUNCH_STREAMS:
+        _LAUNCH_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _LAUNCH_STREAMS[key]
 
 
 class _Bucket:
@@ -113,16 +127,25 @@ class GradAllReducer:
 
     def _launch(self, b: _Bucket):
         b.launched = True
-        if self.world > 1:
+        if self.world > 1 or FORCE_COLLECTIVES:
             if b.flat.is_cuda:
                 # Gradients of one bucket may have been written on different streams (the model runs
-                # its image-level discriminator on a side stream, detector.py): the collective is
-                # ordered after the CURRENT stream only, so make that stream wait for the others.
-                cur = torch.cuda.current_stream(b.flat.device)
-                for s in [torch.cuda.default_stream(b.flat.device)] + list(EXTRA_STREAMS):
-                    if s != cur and s.device == b.flat.device:
-                        cur.wait_stream(s)
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # its image-level discriminator on a side stream, detector.py).  The collective is
+                # ordered after the stream it is issued from, so it is issued from a small LAUNCH
+                # stream that first waits for every gradient-producing stream -- the compute streams
+                # themselves are never made to wait for one another here.
+                dev = b.flat.device
+                launch = _launch_stream(dev)
+                cur = torch.cuda.current_stream(dev)
+                launch.wait_stream(cur)
+                for s in [torch.cuda.default_stream(dev)] + list(EXTRA_STREAMS):
+                    if s != cur and s.device == dev:
+                        launch.wait_stream(s)
+                with torch.cuda.stream(launch):
+                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True)
+            else:
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- step API -------------------------------------------------------------------------------
     def zero_grad(self):
@@ -171,7 +194,7 @@ def init_distributed(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         if backend is None:
             # "nccl" == RCCL on ROCm.  DATR_DIST_BACKEND=gloo lets several ranks share one GPU
             # (functional testing of the multi-process path on a 1-GPU box).

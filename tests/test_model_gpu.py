@@ -176,3 +176,18 @@ def test_training_step_has_no_host_synchronisation(padded):
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.isfinite(loss)
+
+
+def test_data_parallel_step_has_no_host_synchronisation():
+    """The same property with the multi-GPU machinery switched on: a one-rank RCCL process group,
+    the flat-bucket reducer and every collective issued (DATR_DIST_FORCE_COLLECTIVES=1) -- run in a
+    subprocess so that the initialised process group does not leak into other tests."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DATR_DIST_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "sync_audit.py"), "--dist", "--small"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "total synchronising calls in one step: 0" in out.stdout, out.stdout[-2000:]
