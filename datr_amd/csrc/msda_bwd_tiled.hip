@@ -61,7 +61,7 @@ extern "C" void datr_probe_phase_cycles(unsigned long long *out, int reset) {
 
 namespace {
 
-constexpr int kThreads = 512;
+constexpr int kThreads = 768;            // 12 waves; 2 workgroups per CU (LDS) = 6 waves per SIMD
 constexpr int kWaves = kThreads / 64;
 static_assert(kWaves <= 16, "fctl holds 16 per-wave partials per quantity");
 constexpr int kLPR = 8;                 // lanes per 32-channel row (float4 each)
@@ -102,7 +102,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ABL (probe builds only, -DDATR_PROBE): 1 = no LDS adds, 2 = no flush, 4 = no corner gathers,
 // 8 = no grad_loc/grad_attn stores.  0 in product builds.
 template <int ABL>
-__global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void msda_bwd_tiled_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, const DatrTiledMeta meta,
     int S, int M, int P, int split_levels, float *__restrict__ grad_value,
@@ -248,6 +248,10 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
         DATR_TICK(2);
 
         // ---- phase B: gather corners, reduce grad_loc/grad_attn, accumulate grad_value ---------
+        // (kUnroll = 1 since the kernel runs at 6 waves per SIMD -- 80 VGPRs, amdgpu_waves_per_eu --
+        // where occupancy hides the latency better than a second pair in flight did at 4 waves:
+        // 564 -> 544 us per N=2 encoder call; the LDS atomic path is issue-bound per wave,
+        // profiles/r01_probes.md.)
         // kUnroll pairs per group are in flight at once: all their loads (stage, grad_out row,
         // four corner rows) are issued before the first one is consumed, otherwise the chain
         // LDS read -> global gather -> DPP -> LDS add is pure latency at 16 waves per CU.
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_d32(
             DATR_CORNER(8u, 1, 1, c3, f.o3)
 #undef DATR_CORNER
         };
-        constexpr int kUnroll = 2;
+        constexpr int kUnroll = 1;
         for (int base = g; base < npairs; base += kUnroll * kGroups) {
             Inflight f[kUnroll];
 #pragma unroll
