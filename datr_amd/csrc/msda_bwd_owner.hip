@@ -8,7 +8,7 @@
 // many queries on the same object -- atomics on the same rows serialise (183 us per call in the
 // training step for ~2 k queries).
 //
-// This kernel turns the ownership around: a workgroup owns a RANGE OF VALUE ROWS (<= 448
+// This kernel turns the ownership around: a workgroup owns a RANGE OF VALUE ROWS (<= 416
 // consecutive pixels of one level, one head, one image) in LDS and scans ALL samples of that
 // (image, head, level) -- a few thousand, 12 bytes each -- keeping those that touch its range:
 //   * grad_value: every corner that falls in the range is accumulated into the LDS window in
@@ -29,11 +29,11 @@
 
 namespace {
 
-constexpr int kThreads = 512;
+constexpr int kThreads = 768;           // 2 workgroups per CU = 6 waves per SIMD (76 KB of LDS each)
 constexpr int kWaves = kThreads / 64;
 constexpr int kLPR = 8;                 // lanes per 32-channel row (float4 each)
 constexpr int kGroups = kThreads / kLPR;
-constexpr int kRows = 448;              // value rows owned by a workgroup (56 KB of accumulators)
+constexpr int kRows = 416;              // value rows owned by a workgroup (52 KB of accumulators)
 constexpr unsigned kOutOfRange = 0x80000000u;
 
 struct Entry {               // 32 B: a sample that concerns this workgroup
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
 {
     constexpr int D = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Entry *queue = reinterpret_cast<Entry *>(smem);                                // 16 KB
-    int *win = reinterpret_cast<int *>(smem + kThreads * sizeof(Entry));           // 56 KB
+    Entry *queue = reinterpret_cast<Entry *>(smem);                                // 24 KB
+    int *win = reinterpret_cast<int *>(smem + kThreads * sizeof(Entry));           // 52 KB
     int *ctl = reinterpret_cast<int *>(win + kRows * D);                           // [0] queue length
     float *fctl = reinterpret_cast<float *>(ctl + 4);                              // 2 x kWaves
 
