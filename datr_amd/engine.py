@@ -55,7 +55,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             weight_dict = criterion.weight_dict
             losses = weighted_total(loss_dict, weight_dict)
 
-        loss_dict_reduced = reduce_dict(loss_dict)
+        loss_dict_reduced = {k: v.detach() for k, v in reduce_dict(loss_dict).items()}
         scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
         loss_value = sum(scaled.values()).item()
         if not math.isfinite(loss_value):

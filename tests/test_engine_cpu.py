@@ -1,0 +1,133 @@
+"""CPU: two optimizer steps of the burn-in epoch function (datr_amd.engine.train_one_epoch)
+against the reference's own `engine.train_one_epoch` run on the same two batches
+(tests/golden/make_golden_engine.py -> engine_epoch.npz): the loss
+dict of each step, every parameter's change after each clip_grad_norm_(0.1) + AdamW step, the
+returned (averaged) stats, the final parameters and the running prototypes.
+
+The top-900 query selection is the forward pass's discontinuity: after the first optimizer step
+some encoder scores are tied to the last bit and a 1e-7 difference in a gradient swaps their
+RANKS (same set of tokens, different query slots), which moves the second step's losses by
+percents.  So step 0 runs on the build's own selection (and must reproduce the reference's
+exactly on CPU); from step 1 on the reference's selection is substituted, after checking that the
+build selected the same SET of tokens."""
+import numpy as np
+import torch
+
+from helpers import build_model, load_npz, patch_msda_with_oracle, t
+
+
+def noise_of(g, s):
+    return {"label_p": t(g[f"step{s}/noise_label_p"]), "new_label": t(g[f"step{s}/noise_new_label"]),
+            "rand_sign": t(g[f"step{s}/noise_rand_sign"]), "rand_part": t(g[f"step{s}/noise_rand_part"])}
+
+
+class EpochProbe:
+    """Drives `train_one_epoch` over the generator's batches and records what the golden holds:
+    per-step loss dicts, per-step cumulative parameter changes, the build's own selections."""
+
+    def __init__(self, model, criterion, optimizer, g, device, force_from_step):
+        self.model, self.g, self.device = model, g, device
+        self.keys = [str(k) for k in g["param_keys"]]
+        sd = model.state_dict()
+        self.before = {k: sd[k].detach().clone() for k in self.keys}
+        self.losses, self.deltas, self.own_selection = [], [], {}
+        self.step = 0
+        criterion.register_forward_hook(
+            lambda mod, inp, res: self.losses.append({k: float(v) for k, v in res.items()}))
+        real_step = optimizer.step
+
+        def rec_step(*a, **kw):
+            res = real_step(*a, **kw)
+            cur = model.state_dict()
+            self.deltas.append(np.array([float((cur[k].double() - self.before[k].double()).norm())
+                                         for k in self.keys]))
+            return res
+        optimizer.step = rec_step
+        own = model.transformer.select_queries
+
+        def select(scores):
+            mine = own(scores)
+            ref = [t(g[f"step{self.step}/topk_source"]), t(g[f"step{self.step}/topk_target"])]
+            if scores.shape[0] == ref[0].shape[0] + ref[1].shape[0]:       # merged decoder pass
+                self.own_selection[(self.step, "both")] = mine.cpu()
+                chosen = torch.cat(ref, 0)
+            else:
+                j = sum(1 for (s, _) in self.own_selection if s == self.step)
+                self.own_selection[(self.step, ("source", "target")[j])] = mine.cpu()
+                chosen = ref[j]
+            return chosen.to(scores.device) if self.step >= force_from_step else mine
+        model.transformer.select_queries = select
+
+    def loader(self):
+        import synth
+        from datr_amd.nested import nested_tensor_from_tensor_list
+        for s in range(int(self.g["steps"])):
+            imgs, targets = synth.synth_batch(seed=1 + s)
+            self.step = s
+            self.model.dn_noise_override = noise_of(self.g, s)
+            yield nested_tensor_from_tensor_list(imgs), tuple(targets), None, None
+
+    def reference_selection(self, s):
+        return torch.cat([t(self.g[f"step{s}/topk_source"]), t(self.g[f"step{s}/topk_target"])], 0)
+
+    def build_selection(self, s):
+        if (s, "both") in self.own_selection:
+            return self.own_selection[(s, "both")]
+        return torch.cat([self.own_selection[(s, "source")], self.own_selection[(s, "target")]], 0)
+
+    def check_step(self, s, loss_rtol, delta_rtol, skip_counts=False):
+        ref = dict(zip(map(str, self.g[f"step{s}/loss_keys"]), self.g[f"step{s}/loss_values"]))
+        assert set(ref) == set(self.losses[s])
+        for k, v in ref.items():
+            if skip_counts and ("class_error" in k or "cardinality" in k):
+                continue
+            assert abs(self.losses[s][k] - v) <= loss_rtol * abs(v) + 1e-5, (s, k, self.losses[s][k], v)
+        rd = self.g[f"step{s}/delta_norms"]
+        moved = rd > 0
+        assert np.array_equal(self.deltas[s] > 0, moved)       # frozen tensors stay frozen, the rest move
+        np.testing.assert_allclose(self.deltas[s][moved], rd[moved], rtol=delta_rtol)
+
+    def check_final(self, stats, stat_rtol, norm_rtol, delta_cos, skip_counts=False):
+        ref = {str(k): float(v) for k, v in zip(self.g["stat_keys"], self.g["stat_values"])}
+        for k, v in ref.items():
+            assert k in stats, k
+            if skip_counts and ("class_error" in k or "cardinality" in k):
+                continue
+            assert abs(stats[k] - v) <= stat_rtol * abs(v) + 1e-5, (k, stats[k], v)
+        sd = self.model.state_dict()
+        norms = np.array([float(sd[k].double().norm()) for k in self.keys])
+        np.testing.assert_allclose(norms, self.g["param_norms"], rtol=norm_rtol, atol=1e-7)
+        for name, ref_delta in self.g.items():
+            if not name.startswith("delta::"):
+                continue
+            k = name[len("delta::"):]
+            d = (sd[k] - self.before[k]).double().flatten().cpu()
+            r = t(ref_delta).double().flatten()
+            cos = float(torch.dot(d, r) / (d.norm() * r.norm()))
+            assert cos >= delta_cos, (k, cos)
+
+
+def test_two_burn_in_steps_match_reference_epoch(monkeypatch):
+    from datr_amd.config import get_param_dict
+    from datr_amd.engine import train_one_epoch
+    patch_msda_with_oracle(monkeypatch, kind="grid_sample")
+    g = load_npz("engine_epoch.npz")
+    args, model, criterion, _ = build_model()
+    assert args.clip_max_norm == float(g["clip_max_norm"]) and args.lr == float(g["lr"])
+    assert args.lr_backbone == float(g["lr_backbone"]) and args.weight_decay == float(g["weight_decay"])
+    model.merge_encoder_passes = False                 # the reference's call structure
+    optimizer = torch.optim.AdamW(get_param_dict(args, model), lr=args.lr, weight_decay=args.weight_decay)
+    probe = EpochProbe(model, criterion, optimizer, g, torch.device("cpu"), force_from_step=1)
+    stats = train_one_epoch(model, criterion, probe.loader(), optimizer, torch.device("cpu"), 0,
+                            args.clip_max_norm, args=args)
+    assert len(probe.losses) == 2 and len(probe.deltas) == 2
+    # step 0: own selection, bit-exact indices, losses and parameter changes to rounding
+    assert torch.equal(probe.build_selection(0), probe.reference_selection(0))
+    probe.check_step(0, loss_rtol=1e-5, delta_rtol=2e-4)
+    # step 1: the same SET of tokens (ranks of tied scores may swap), then the reference's order
+    mine, ref = probe.build_selection(1), probe.reference_selection(1)
+    assert torch.equal(mine.sort(1)[0], ref.sort(1)[0])
+    probe.check_step(1, loss_rtol=5e-4, delta_rtol=5e-3)
+    probe.check_final(stats, stat_rtol=5e-4, norm_rtol=5e-6, delta_cos=0.9999)
+    torch.testing.assert_close(model.global_proto, t(g["global_proto"]), rtol=1e-3, atol=5e-4)
+    torch.testing.assert_close(model.Amount, t(g["Amount"]))
