@@ -38,6 +38,8 @@ _SIGNATURES = {
     "datr_normalize_pad_u8_f32": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
     "datr_lsap_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "datr_colsum_f32": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "datr_wgrad_k256_f32": [_vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "datr_gemm_k256_f32": [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp],
     "datr_conv3x3_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
                                       ctypes.c_float, _vp, _vp],
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
@@ -70,6 +72,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_add_layernorm_partial_floats.argtypes = [_i64]
     lib.datr_relu_bwd_bias_partial_rows.restype = ctypes.c_int64
     lib.datr_relu_bwd_bias_partial_rows.argtypes = [_i64]
+    lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64
+    lib.datr_wgrad_k256_scratch_floats.argtypes = []
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes

@@ -195,6 +195,29 @@ int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial, 
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Tall-skinny fp32 MFMA GEMM with K = 256: y[M, N] = x[M, 256] * B[256, N] (+ bias[N]); the
+ * value / output / sampling-offset projections of MSDeformAttn
+ * (/root/reference/models/dino/ops/modules/ms_deform_attn.py:92-95,118-124: nn.Linear(256, .) on
+ * all encoder tokens) and their data gradients.  B[k][n] = b[k * ldk + n * ldn]:
+ * (ldk, ldn) = (1, 256) computes x W^T for a row-major weight W[N][256] (F.linear forward),
+ * (N, 1) computes dy W for W[256][N] (its data gradient when out_features == 256).
+ * N % 128 == 0, N <= 2048; x, y contiguous row-major; bias may be NULL.  Exact fp32
+ * (v_mfma_f32_32x32x2_f32), K summed in ascending pairs (j, j + 16) per 32-chunk. */
+int datr_gemm_k256_f32(const float *x, const float *b, int64_t ldk, int64_t ldn,
+                       const float *bias, int64_t M, int64_t N, float *y, void *stream);
+
+/* Weight and bias gradient of a 256 -> 256 linear layer over M rows (the MSDeformAttn value /
+ * output projections and enc_output over all encoder tokens; autograd's `dy.t().mm(x)` and
+ * `dy.sum(0)`): dw[256, 256] = dy^T x, db[256] = column sums of dy (db may be NULL).  dy, x:
+ * contiguous [M, 256].  The rows are split over one workgroup per CU, partial products go to
+ * `scratch` (>= datr_wgrad_k256_scratch_floats() floats, caller-owned, reusable by later calls on
+ * the same stream) and are added in a fixed order: deterministic. */
+#define DATR_WGRAD_K256_MAX_BLOCKS 256
+int64_t datr_wgrad_k256_scratch_floats(void);
+int datr_wgrad_k256_f32(const float *dy, const float *x, int64_t M, float *scratch, float *dw,
+                        float *db, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hungarian matching on the device: all of a step's rectangular assignment problems in one
  * launch, indices left on the device (no host synchronisation).  Replaces `C.cpu()` +
  * scipy.optimize.linear_sum_assignment per image (/root/reference/models/dino/matcher.py:91-95);
