@@ -266,8 +266,10 @@ class SetCriterion(nn.Module):
                 sums = focal_loss_sums(logits.reshape(G, B * Q, C), target_classes.view(G, B * Q),
                                        self.focal_alpha, 2.0)
                 loss_ce = sums / Q / num_boxes * Q
-                for g in range(G):
-                    res[g]["loss_ce"] = loss_ce[g]
+                # unbind, not loss_ce[g]: ONE backward node (a stack of the G scalar gradients)
+                # instead of G select-backwards (zeros + scatter + accumulate each)
+                for g, v in enumerate(loss_ce.unbind(0)):
+                    res[g]["loss_ce"] = v
                 if log_first:
                     res[0]["class_error"] = 100 - accuracy(
                         logits[0][b_idx[:n_first], q_idx[:n_first]], matched_cls[:n_first])[0]
@@ -283,16 +285,17 @@ class SetCriterion(nn.Module):
                 with torch.no_grad():
                     loss_xy = per_g(l1[..., :2].sum(-1)) / num_boxes
                     loss_hw = per_g(l1[..., 2:].sum(-1)) / num_boxes
-                for g in range(G):
-                    res[g]["loss_bbox"], res[g]["loss_giou"] = loss_bbox[g], loss_giou[g]
-                    res[g]["loss_xy"], res[g]["loss_hw"] = loss_xy[g], loss_hw[g]
+                for g, (lb, lg, lx, lh) in enumerate(zip(loss_bbox.unbind(0), loss_giou.unbind(0),
+                                                         loss_xy.unbind(0), loss_hw.unbind(0))):
+                    res[g]["loss_bbox"], res[g]["loss_giou"] = lb, lg
+                    res[g]["loss_xy"], res[g]["loss_hw"] = lx, lh
             elif loss == "cardinality":
                 with torch.no_grad():
                     lengths = _device_lengths(tuple(counts), device)
                     card_pred = (logits.argmax(-1) != C - 1).sum(-1).float()         # [G, B]
                     card_err = (card_pred - lengths[None]).abs().mean(-1)
-                for g in range(G):
-                    res[g]["cardinality_error"] = card_err[g]
+                for g, v in enumerate(card_err.unbind(0)):
+                    res[g]["cardinality_error"] = v
             else:
                 raise AssertionError(f"do you really want to compute {loss} loss?")
         return res

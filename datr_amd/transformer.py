@@ -73,11 +73,35 @@ def _activation(name: str):
     return table[name]
 
 
+_DIM_T = {}
+
+
+def _sine_temperatures(device) -> Tensor:
+    t = _DIM_T.get(device)
+    if t is None:
+        k = torch.arange(128, dtype=torch.float32, device=device)
+        t = _DIM_T[device] = 10000 ** (2 * torch.div(k, 2, rounding_mode="floor") / 128)
+    return t
+
+
 def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
     """[nq, bs, 2|4] normalised (x, y[, w, h]) -> [nq, bs, 128 * last_dim] sine embedding in
-    the order (y, x[, w, h]); temperature 10000, 128 features per coordinate."""
-    k = torch.arange(128, dtype=torch.float32, device=pos_tensor.device)
-    dim_t = 10000 ** (2 * torch.div(k, 2, rounding_mode="floor") / 128)
+    the order (y, x[, w, h]); temperature 10000, 128 features per coordinate.  Device float32
+    boxes that carry no gradient (the decoder's case: boxes are detached between layers) take
+    the one-launch kernel csrc/sine_embed.hip; everything else the torch formulation."""
+    if pos_tensor.size(-1) not in (2, 4):
+        raise ValueError(f"Unknown pos_tensor shape(-1):{pos_tensor.size(-1)}")
+    dim_t = _sine_temperatures(pos_tensor.device)
+    if pos_tensor.is_cuda and pos_tensor.dtype == torch.float32 and not pos_tensor.requires_grad:
+        from . import _native
+        nq, bs, nc = pos_tensor.shape
+        pos = pos_tensor.contiguous()
+        out = torch.empty(nq, bs, 128 * nc, device=pos.device, dtype=torch.float32)
+        with torch.cuda.device(pos.device):
+            rc = _native.lib.datr_sine_embed_f32(pos.data_ptr(), dim_t.data_ptr(), nq * bs, nc,
+                                                 out.data_ptr(), _native.current_stream_ptr(pos.device))
+        _native.check(rc, "sine_embed")
+        return out
 
     def embed(coord):
         p = (coord * (2 * math.pi))[:, :, None] / dim_t
@@ -86,45 +110,57 @@ def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
     parts = [embed(pos_tensor[:, :, 1]), embed(pos_tensor[:, :, 0])]
     if pos_tensor.size(-1) == 4:
         parts += [embed(pos_tensor[:, :, 2]), embed(pos_tensor[:, :, 3])]
-    elif pos_tensor.size(-1) != 2:
-        raise ValueError(f"Unknown pos_tensor shape(-1):{pos_tensor.size(-1)}")
     return torch.cat(parts, dim=2)
 
 
+_PROPOSALS = {}
+
+
 def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor,
-                                 spatial_shapes, learnedwh=None):
+                                 spatial_shapes, learnedwh=None, no_padding: bool = False):
     """One anchor per encoder token: centre = pixel centre / valid extent, size 0.05 * 2^level;
     anchors outside (0.01, 0.99) or on padding become +inf in logit space and their memory is
-    zeroed.  `spatial_shapes` is a list of (H, W) python ints or an int64 tensor."""
+    zeroed.  `spatial_shapes` is a list of (H, W) python ints or an int64 tensor.
+    `no_padding=True` (the caller knows the mask is all False, without looking at it): anchors
+    and validity depend on the shapes only and are cached -- 75 small launches per call."""
     N = memory.shape[0]
     shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist()
               if isinstance(spatial_shapes, Tensor) else spatial_shapes)]
-    proposals = []
-    cur = 0
-    for lvl, (H, W) in enumerate(shapes):
-        m = memory_padding_mask[:, cur:cur + H * W].view(N, H, W, 1)
-        valid_H = torch.sum(~m[:, :, 0, 0], 1)
-        valid_W = torch.sum(~m[:, 0, :, 0], 1)
-        gy, gx = torch.meshgrid(
-            torch.linspace(0, H - 1, H, dtype=torch.float32, device=memory.device),
-            torch.linspace(0, W - 1, W, dtype=torch.float32, device=memory.device),
-            indexing="ij")
-        grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
-        scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N, 1, 1, 2)
-        grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
-        if learnedwh is not None:
-            wh = torch.ones_like(grid) * learnedwh.sigmoid() * (2.0 ** lvl)
-        else:
-            wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
-        proposals.append(torch.cat((grid, wh), -1).view(N, -1, 4))
-        cur += H * W
-    output_proposals = torch.cat(proposals, 1)
-    ok = ((output_proposals > 0.01) & (output_proposals < 0.99)).all(-1, keepdim=True)
-    output_proposals = torch.log(output_proposals / (1 - output_proposals))
-    output_proposals = output_proposals.masked_fill(memory_padding_mask.unsqueeze(-1), float("inf"))
-    output_proposals = output_proposals.masked_fill(~ok, float("inf"))
-    output_memory = memory.masked_fill(memory_padding_mask.unsqueeze(-1), 0.0)
-    output_memory = output_memory.masked_fill(~ok, 0.0)
+    key = (N, tuple(shapes), str(memory.device)) if no_padding and learnedwh is None else None
+    cached = _PROPOSALS.get(key) if key is not None else None
+    if cached is None:
+        proposals = []
+        cur = 0
+        for lvl, (H, W) in enumerate(shapes):
+            m = memory_padding_mask[:, cur:cur + H * W].view(N, H, W, 1)
+            valid_H = torch.sum(~m[:, :, 0, 0], 1)
+            valid_W = torch.sum(~m[:, 0, :, 0], 1)
+            gy, gx = torch.meshgrid(
+                torch.linspace(0, H - 1, H, dtype=torch.float32, device=memory.device),
+                torch.linspace(0, W - 1, W, dtype=torch.float32, device=memory.device),
+                indexing="ij")
+            grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
+            scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N, 1, 1, 2)
+            grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
+            if learnedwh is not None:
+                wh = torch.ones_like(grid) * learnedwh.sigmoid() * (2.0 ** lvl)
+            else:
+                wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+            proposals.append(torch.cat((grid, wh), -1).view(N, -1, 4))
+            cur += H * W
+        output_proposals = torch.cat(proposals, 1)
+        ok = ((output_proposals > 0.01) & (output_proposals < 0.99)).all(-1, keepdim=True)
+        output_proposals = torch.log(output_proposals / (1 - output_proposals))
+        # masked_fill(padding) then masked_fill(~ok) == one masked_fill with the union
+        invalid = memory_padding_mask.unsqueeze(-1) | ~ok
+        output_proposals = output_proposals.masked_fill(invalid, float("inf"))
+        if key is not None:
+            if len(_PROPOSALS) > 16:
+                _PROPOSALS.clear()
+            _PROPOSALS[key] = (output_proposals, invalid)
+    else:
+        output_proposals, invalid = cached
+    output_memory = memory.masked_fill(invalid, 0.0)
     return output_memory, output_proposals
 
 
@@ -495,7 +531,7 @@ class DeformableTransformer(nn.Module):
         if self.two_stage_type == "standard":
             input_hw = self.two_stage_wh_embedding.weight[0] if self.two_stage_learn_wh else None
             output_memory, output_proposals = gen_encoder_output_proposals(
-                memory, mask_flatten, shapes_list, input_hw)
+                memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding)
             output_memory = self.enc_output_norm(self.enc_output(output_memory))
             enc_class = self.enc_out_class_embed(output_memory)
             enc_coord = self.enc_out_bbox_embed(output_memory) + output_proposals   # logits

@@ -195,6 +195,15 @@ int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial, 
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sine embedding of the decoder's reference boxes: `gen_sineembed_for_position`
+ * (/root/reference/models/dino/utils.py:138-163).  pos [rows, ncoord] (ncoord = 2: (x, y) or
+ * 4: (x, y, w, h)), dim_t [128] = 10000^(2 floor(k / 2) / 128), out [rows, 128 * ncoord] in the
+ * reference's order (y, x[, w, h]); out_k = sin / cos of (coord * 2 pi) / dim_t[k] for even / odd k.
+ * Forward only (the boxes are detached between decoder layers). */
+int datr_sine_embed_f32(const float *pos, const float *dim_t, int64_t rows, int64_t ncoord,
+                        float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Tall-skinny fp32 MFMA GEMM with K = 256: y[M, N] = x[M, 256] * B[256, N] (+ bias[N]); the
  * value / output / sampling-offset projections of MSDeformAttn
  * (/root/reference/models/dino/ops/modules/ms_deform_attn.py:92-95,118-124: nn.Linear(256, .) on

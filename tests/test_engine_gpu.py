@@ -35,6 +35,6 @@ def test_two_burn_in_steps_on_device():
     # level may flip a whole lr -- norms of the changes still agree to a percent
     probe.check_step(0, loss_rtol=2e-3, delta_rtol=1e-2, skip_counts=True)
     probe.check_step(1, loss_rtol=5e-3, delta_rtol=3e-2, skip_counts=True)
-    probe.check_final(stats, stat_rtol=5e-3, norm_rtol=2e-5, delta_cos=0.995, skip_counts=True)
+    probe.check_final(stats, stat_rtol=5e-3, norm_rtol=1e-4, delta_cos=0.995, skip_counts=True)
     torch.testing.assert_close(model.global_proto.cpu(), t(g["global_proto"]), rtol=5e-3, atol=2e-3)
     torch.testing.assert_close(model.Amount.cpu(), t(g["Amount"]), rtol=0, atol=3.0)

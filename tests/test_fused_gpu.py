@@ -249,3 +249,31 @@ def test_fast_linear_uses_wgrad_kernel_and_matches_autograd():
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=2e-3)
     torch.testing.assert_close(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("nc", [2, 4])
+def test_sine_embed_kernel_matches_torch_formulation(nc):
+    """csrc/sine_embed.hip against the torch restatement of gen_sineembed_for_position
+    (utils.py:138-163), which a tensor that requires grad still takes."""
+    from datr_amd.transformer import gen_sineembed_for_position
+    dev = torch.device("cuda:0")
+    torch.manual_seed(nc)
+    pos = torch.rand(1100, 4, nc, device=dev) * 1.2 - 0.1
+    fused = gen_sineembed_for_position(pos)
+    ref = gen_sineembed_for_position(pos.clone().requires_grad_(True)).detach()
+    assert fused.shape == (1100, 4, 128 * nc)
+    torch.testing.assert_close(fused, ref, rtol=0, atol=2e-6)
+
+
+def test_cached_proposals_equal_uncached():
+    from datr_amd.transformer import gen_encoder_output_proposals
+    dev = torch.device("cuda:0")
+    shapes = [(20, 27), (10, 14), (5, 7), (3, 4)]
+    S = sum(h * w for h, w in shapes)
+    torch.manual_seed(0)
+    mem = torch.randn(2, S, 256, device=dev)
+    mask = torch.zeros(2, S, dtype=torch.bool, device=dev)
+    m0, p0 = gen_encoder_output_proposals(mem, mask, shapes)
+    for _ in range(2):                                     # second call hits the cache
+        m1, p1 = gen_encoder_output_proposals(mem, mask, shapes, no_padding=True)
+        assert torch.equal(m0, m1) and torch.equal(p0, p1)

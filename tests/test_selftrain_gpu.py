@@ -56,4 +56,4 @@ def test_teacher_student_step_on_device():
     assert last["num_pseudo_images"] == 1 and last["loss_self_training_sum"] > 0
     sd = model.state_dict()
     norms = np.array([float(sd[str(k)].double().norm()) for k in g["param_keys"]])
-    np.testing.assert_allclose(norms, g["param_norms"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(norms, g["param_norms"], rtol=5e-5, atol=1e-7)
