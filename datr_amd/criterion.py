@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import boxes as box_ops
+from .focal import MAX_BOX_LOSS_PAIRS, box_loss_sums
 from .focal import sigmoid_focal_loss_sums as focal_loss_sums
 from .nested import accuracy, get_world_size, is_dist_avail_and_initialized
 
@@ -42,6 +43,9 @@ def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: f
 
 
 _STATIC = {}
+
+
+FUSED_BOX_LOSS = True
 
 
 def weighted_total(loss_dict, weight_dict):
@@ -276,6 +280,16 @@ class SetCriterion(nn.Module):
             elif loss == "boxes":
                 src = boxes[g_idx, b_idx, q_idx]
                 tgt = boxes_cat[t_idx]
+                if FUSED_BOX_LOSS and src.is_cuda and src.dtype == torch.float32 \
+                        and 0 < src.shape[0] <= MAX_BOX_LOSS_PAIRS and G <= 64:
+                    # one launch each way instead of ~125 (csrc/box_loss.hip)
+                    sums = box_loss_sums(src, tgt, g_idx, G) / num_boxes
+                    lb, lg, lx, lh = sums.unbind(0)
+                    for g, (vb, vg, vx, vh) in enumerate(zip(lb.unbind(0), lg.unbind(0),
+                                                             lx.detach().unbind(0), lh.detach().unbind(0))):
+                        res[g]["loss_bbox"], res[g]["loss_giou"] = vb, vg
+                        res[g]["loss_xy"], res[g]["loss_hw"] = vx, vh
+                    continue
                 l1 = F.l1_loss(src, tgt, reduction="none")
                 giou = box_ops.generalized_box_iou_pairs(box_ops.box_cxcywh_to_xyxy(src),
                                                          box_ops.box_cxcywh_to_xyxy(tgt))

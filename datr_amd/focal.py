@@ -62,3 +62,45 @@ def sigmoid_focal_loss_sums(logits: torch.Tensor, target: torch.Tensor, alpha: f
     if logits.dtype != torch.float32:
         raise RuntimeError(f"sigmoid_focal_loss_sums: float32 only, got {logits.dtype}")
     return _FocalSums.apply(logits.contiguous(), target.to(torch.int64).contiguous(), alpha, gamma)
+
+
+MAX_BOX_LOSS_PAIRS = 3072          # DATR_BOX_LOSS_MAX_PAIRS
+
+
+class _BoxLossSums(Function):
+    """[4, G] per-set sums of (L1, 1 - GIoU, L1 of xy, L1 of wh) over matched pairs
+    (csrc/box_loss.hip); gradient to the predicted boxes through rows 0 and 1."""
+
+    @staticmethod
+    def forward(ctx, src, tgt, group, G):
+        src, tgt, group = src.contiguous(), tgt.contiguous(), group.contiguous()
+        sums = torch.empty(4, G, dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            rc = _native.lib.datr_box_loss_forward_f32(
+                src.data_ptr(), tgt.data_ptr(), group.data_ptr(), src.shape[0], G, sums.data_ptr(),
+                _native.current_stream_ptr(src.device))
+        _native.check(rc, "box_loss_forward")
+        ctx.save_for_backward(src, tgt, group)
+        return sums
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_sums):
+        src, tgt, group = ctx.saved_tensors
+        g = grad_sums.contiguous().float()
+        d_src = torch.empty_like(src)
+        with torch.cuda.device(src.device):
+            rc = _native.lib.datr_box_loss_backward_f32(
+                src.data_ptr(), tgt.data_ptr(), group.data_ptr(), g[0].data_ptr(), g[1].data_ptr(),
+                src.shape[0], d_src.data_ptr(), _native.current_stream_ptr(src.device))
+        _native.check(rc, "box_loss_backward")
+        return d_src, None, None, None
+
+
+def box_loss_sums(src: torch.Tensor, tgt: torch.Tensor, group: torch.Tensor, G: int) -> torch.Tensor:
+    """src, tgt [P, 4] cxcywh fp32 on the device, group [P] int64 in [0, G) -> [4, G] sums of the
+    L1 distance, of 1 - GIoU(xyxy(src), xyxy(tgt)) (box_ops.py:40-63, 1e-6 terms included), and
+    of the xy / wh halves of the L1, per prediction set.  Rows 2, 3 are for logging: no gradient."""
+    assert src.is_cuda and src.dtype == torch.float32 and src.shape == tgt.shape and src.shape[-1] == 4
+    assert 0 < src.shape[0] <= MAX_BOX_LOSS_PAIRS and group.dtype == torch.int64
+    return _BoxLossSums.apply(src, tgt.detach(), group, int(G))

@@ -195,6 +195,20 @@ int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial, 
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Box regression losses of SetCriterion (`loss_boxes`, /root/reference/models/dino/dino.py:553-577,
+ * with box_ops.py:9-63) for P matched pairs belonging to G prediction sets: src / tgt [P, 4]
+ * cxcywh, group [P] int64 in [0, G).  forward: sums [4, G] = per-set sums of the L1 distance,
+ * of (1 - GIoU), and of the xy / wh halves of the L1 (callers divide by num_boxes).
+ * backward: d_src [P, 4] given the gradients d_l1 [G], d_giou [G] of the first two rows.
+ * P <= DATR_BOX_LOSS_MAX_PAIRS, G <= 64.  Deterministic. */
+#define DATR_BOX_LOSS_MAX_PAIRS 3072
+int datr_box_loss_forward_f32(const float *src, const float *tgt, const int64_t *group, int64_t P,
+                              int64_t G, float *sums, void *stream);
+int datr_box_loss_backward_f32(const float *src, const float *tgt, const int64_t *group,
+                               const float *d_l1, const float *d_giou, int64_t P, float *d_src,
+                               void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Sine embedding of the decoder's reference boxes: `gen_sineembed_for_position`
  * (/root/reference/models/dino/utils.py:138-163).  pos [rows, ncoord] (ncoord = 2: (x, y) or
  * 4: (x, y, w, h)), dim_t [128] = 10000^(2 floor(k / 2) / 128), out [rows, 128 * ncoord] in the

@@ -46,3 +46,41 @@ def test_focal_extreme_logits_and_empty():
     assert empty.shape == (4,) and torch.count_nonzero(empty) == 0
     with pytest.raises(RuntimeError, match="CPU"):
         sigmoid_focal_loss_sums(torch.zeros(1, 2, 3), torch.zeros(1, 2, dtype=torch.long))
+
+
+def _torch_box_losses(src, tgt, group, G):
+    """The op sequence of SetCriterion.loss_boxes (dino.py:553-577) per prediction set."""
+    import torch.nn.functional as F
+    from datr_amd import boxes as box_ops
+    l1 = F.l1_loss(src, tgt, reduction="none")
+    giou = box_ops.generalized_box_iou_pairs(box_ops.box_cxcywh_to_xyxy(src), box_ops.box_cxcywh_to_xyxy(tgt))
+    per_g = lambda v: torch.zeros(G, device=src.device).index_add_(0, group, v)
+    return torch.stack([per_g(l1.sum(-1)), per_g(1 - giou), per_g(l1[..., :2].sum(-1)),
+                        per_g(l1[..., 2:].sum(-1))])
+
+
+@pytest.mark.parametrize("P,G", [(140, 7), (1200, 6), (3, 1), (3072, 13)])
+def test_fused_box_losses_match_torch_ops(P, G):
+    from datr_amd.focal import box_loss_sums
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(P + G)
+    src = torch.cat([torch.rand(P, 2, generator=gen), torch.rand(P, 2, generator=gen) * 0.4 + 0.01], 1)
+    tgt = torch.cat([torch.rand(P, 2, generator=gen), torch.rand(P, 2, generator=gen) * 0.4 + 0.01], 1)
+    if P >= 3:
+        src[0] = tgt[0]                                   # identical boxes: every max / min ties
+        src[1] = torch.tensor([0.1, 0.1, 0.05, 0.05])     # disjoint boxes: empty intersection
+        tgt[1] = torch.tensor([0.8, 0.8, 0.10, 0.10])
+        src[2, 0] = tgt[2, 0]                             # one coordinate equal: |x|' at 0
+    group = torch.randint(0, G, (P,), generator=gen)
+    src, tgt, group = src.to(dev), tgt.to(dev), group.to(dev)
+    a = src.clone().requires_grad_(True)
+    b = src.clone().requires_grad_(True)
+    fused = box_loss_sums(a, tgt, group, G)
+    ref = _torch_box_losses(b, tgt, group, G)
+    torch.testing.assert_close(fused, ref, rtol=2e-5, atol=2e-5)
+    w = torch.rand(2, G, generator=gen).to(dev) + 0.5
+    (fused[:2] * w).sum().backward()
+    (ref[:2] * w).sum().backward()
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-5)
+    again = box_loss_sums(src, tgt, group, G)
+    assert torch.equal(again, fused.detach())             # deterministic
