@@ -54,19 +54,23 @@ def device_lsap_supported(nq: int, sizes) -> bool:
     return nq <= 1024 and (not sizes or max(sizes) < nq)
 
 
-def solve_lsap_device(C: torch.Tensor, sizes):
-    """C [G, B, nq, sum(sizes)] fp32 on the device -> (q_idx, t_idx, status): q_idx / t_idx
-    [G, sum(sizes)] int64 on the device (image b's pairs at columns offsets[b]:offsets[b+1],
-    query indices ascending -- what SciPy returns), status [G*B] int32 (0 = ok).  No host sync."""
+def solve_lsap_device(C: torch.Tensor, sizes, transposed: bool = False):
+    """C [G, B, nq, sum(sizes)] fp32 on the device (or, with `transposed`, [G, B, sum(sizes), nq]
+    contiguous) -> (q_idx, t_idx, status): q_idx / t_idx [G, sum(sizes)] int64 on the device
+    (image b's pairs at columns offsets[b]:offsets[b+1], query indices ascending -- what SciPy
+    returns), status [G*B] int32 (0 = ok).  No host sync."""
     from . import _native
-    G, B, nq, Tsum = C.shape
+    if transposed:
+        G, B, Tsum, nq = C.shape
+    else:
+        G, B, nq, Tsum = C.shape
     dev = C.device
     q_idx = torch.zeros(G, Tsum, dtype=torch.int64, device=dev)
     t_idx = torch.zeros(G, Tsum, dtype=torch.int64, device=dev)
     status = torch.zeros(max(G * B, 1), dtype=torch.int32, device=dev)
     if G * B == 0 or Tsum == 0:
         return q_idx, t_idx, status
-    Ct = C.transpose(-1, -2).contiguous()
+    Ct = C.contiguous() if transposed else C.transpose(-1, -2).contiguous()
     offsets = _device_offsets(sizes, dev)
     with torch.cuda.device(dev):
         rc = _native.lib.datr_lsap_f32(Ct.data_ptr(), offsets.data_ptr(), G, B, Tsum, nq,
@@ -74,6 +78,9 @@ def solve_lsap_device(C: torch.Tensor, sizes):
                                        status.data_ptr(), _native.current_stream_ptr(dev))
     _native.check(rc, "lsap")
     return q_idx, t_idx, status
+
+
+FUSED_COST = True      # device cost matrix in one launch (csrc/match_cost.hip)
 
 
 class IndexSets(list):
@@ -123,8 +130,32 @@ class HungarianMatcher(nn.Module):
     poison = None
     _boxes_ok = None
 
-    def _indices_from_device(self, C, sizes):
-        q_idx, t_idx, status = solve_lsap_device(C, sizes)
+    @torch.no_grad()
+    def cost_matrix_transposed(self, logits, boxes, targets):
+        """[sets, sum_i T_i, nq] cost for `sets` blocks of nq queries (logits [sets, nq, C], boxes
+        [sets, nq, 4] on the device) in ONE launch (csrc/match_cost.hip): the same entries as
+        cost_matrix(), stored targets x queries as the device solver reads them.  Also sets
+        `_boxes_ok`."""
+        from . import _native
+        sets, nq, C = logits.shape
+        tgt_ids = torch.cat([v["labels"] for v in targets]).contiguous()
+        tgt_bbox = torch.cat([v["boxes"] for v in targets]).float().contiguous()
+        T = tgt_ids.shape[0]
+        logits, boxes = logits.float().contiguous(), boxes.float().contiguous()
+        cost_t = torch.empty(sets, T, nq, dtype=torch.float32, device=logits.device)
+        ok = torch.ones(1, dtype=torch.int32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = _native.lib.datr_match_cost_f32(
+                logits.data_ptr(), boxes.data_ptr(), tgt_ids.data_ptr(), tgt_bbox.data_ptr(), sets, nq,
+                T, C, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou),
+                float(self.focal_alpha), cost_t.data_ptr(), ok.data_ptr(),
+                _native.current_stream_ptr(logits.device))
+        _native.check(rc, "match_cost")
+        self._boxes_ok = ok[0] != 0
+        return cost_t
+
+    def _indices_from_device(self, C, sizes, transposed=False):
+        q_idx, t_idx, status = solve_lsap_device(C, sizes, transposed)
         bad = status.any() if self._boxes_ok is None else (status.any() | ~self._boxes_ok)
         self.poison = torch.where(bad, float("nan"), 0.0)
         out = IndexSets()
@@ -156,6 +187,13 @@ class HungarianMatcher(nn.Module):
         the per-image (row_idx, col_idx) pairs -- identical to calling forward() on each."""
         G = len(outputs_list)
         bs, nq = outputs_list[0]["pred_logits"].shape[:2]
+        sizes = [len(v["boxes"]) for v in targets]
+        if FUSED_COST and outputs_list[0]["pred_logits"].is_cuda and sum(sizes) > 0 \
+                and device_lsap_supported(nq, sizes):
+            Ct = self.cost_matrix_transposed(
+                torch.cat([o["pred_logits"] for o in outputs_list], 0),
+                torch.cat([o["pred_boxes"] for o in outputs_list], 0), targets)
+            return self._indices_from_device(Ct.view(G, bs, -1, nq), sizes, transposed=True)
         stacked = {"pred_logits": torch.cat([o["pred_logits"] for o in outputs_list], 0),
                    "pred_boxes": torch.cat([o["pred_boxes"] for o in outputs_list], 0)}
         C = self.cost_matrix(stacked, targets).view(G, bs, nq, -1)

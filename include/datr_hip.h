@@ -195,6 +195,17 @@ int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial, 
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Cost matrix of the Hungarian matcher (/root/reference/models/dino/matcher.py:48-88) for `sets`
+ * = (prediction sets x images) blocks of nq queries against all T ground-truth boxes of the
+ * batch: logits [sets * nq, C], boxes [sets * nq, 4] cxcywh, tgt_ids [T] int64, tgt_boxes [T, 4].
+ * cost_t [sets, T, nq] = TRANSPOSED cost (what datr_lsap_f32 reads).  *boxes_ok (caller sets it
+ * to 1) is cleared if any box is degenerate (the reference asserts, box_ops.py:52-53). */
+int datr_match_cost_f32(const float *logits, const float *boxes, const int64_t *tgt_ids,
+                        const float *tgt_boxes, int64_t sets, int64_t nq, int64_t T, int64_t C,
+                        float w_class, float w_bbox, float w_giou, float alpha, float *cost_t,
+                        int32_t *boxes_ok, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Box regression losses of SetCriterion (`loss_boxes`, /root/reference/models/dino/dino.py:553-577,
  * with box_ops.py:9-63) for P matched pairs belonging to G prediction sets: src / tgt [P, 4]
  * cxcywh, group [P] int64 in [0, G).  forward: sums [4, G] = per-set sums of the L1 distance,

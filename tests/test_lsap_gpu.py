@@ -88,3 +88,40 @@ def test_invalid_costs_are_flagged():
     C[0, 1, 3, 5] = float("nan")
     _, _, status = run(C, [4, 4])
     assert status.tolist() == [0, 1]
+
+
+def test_fused_cost_matrix_matches_torch_ops_and_gives_the_same_matching():
+    """csrc/match_cost.hip against HungarianMatcher.cost_matrix (the reference's op sequence,
+    matcher.py:48-88), and forward_many with / without it."""
+    from datr_amd import matcher as M
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    G, B, nq, C = 7, 2, 900, 9
+    outs = [{"pred_logits": (torch.randn(B, nq, C, generator=gen) * 2 - 2).to(dev),
+             "pred_boxes": torch.cat([torch.rand(B, nq, 2, generator=gen),
+                                      torch.rand(B, nq, 2, generator=gen) * 0.5 + 0.01], -1).to(dev)}
+            for _ in range(G)]
+    targets = [{"labels": torch.randint(1, 9, (n,), generator=gen).to(dev),
+                "boxes": torch.cat([torch.rand(n, 2, generator=gen) * 0.6 + 0.2,
+                                    torch.rand(n, 2, generator=gen) * 0.2 + 0.05], -1).to(dev)}
+               for n in (10, 7)]
+    m = M.HungarianMatcher(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0, focal_alpha=0.25)
+    logits = torch.cat([o["pred_logits"] for o in outs], 0)
+    boxes = torch.cat([o["pred_boxes"] for o in outs], 0)
+    ct = m.cost_matrix_transposed(logits, boxes, targets)
+    assert bool(m._boxes_ok)
+    ref = m.cost_matrix({"pred_logits": logits, "pred_boxes": boxes}, targets)        # [G*B, nq, T]
+    torch.testing.assert_close(ct, ref.transpose(1, 2), rtol=1e-5, atol=1e-5)
+    fused = m.forward_many(outs, targets)
+    M.FUSED_COST = False
+    try:
+        plain = m.forward_many(outs, targets)
+    finally:
+        M.FUSED_COST = True
+    for a, b in zip(fused, plain):
+        for (q1, t1), (q2, t2) in zip(a, b):
+            assert torch.equal(q1, q2) and torch.equal(t1, t2)
+    # a degenerate box (negative width) clears the validity flag
+    boxes[3, 5, 2] = -0.1
+    m.cost_matrix_transposed(logits, boxes, targets)
+    assert not bool(m._boxes_ok)
