@@ -43,10 +43,12 @@ def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, lab
 
     labels = torch.cat([t["labels"] for t in targets])
     boxes = torch.cat([t["boxes"] for t in targets])
-    batch_idx = torch.cat([torch.full_like(t["labels"].long(), i) for i, t in enumerate(targets)])
+    single_pad = max_gt
+    pad_size = int(single_pad * 2 * groups)
+    static = _static_parts(tuple(counts), groups, num_queries, device)
 
     known_labels = labels.repeat(2 * groups, 1).view(-1)
-    known_bid = batch_idx.repeat(2 * groups, 1).view(-1)
+    known_bid = static["known_bid"]
     known_bboxs = boxes.repeat(2 * groups, 1)
     noised_labels = known_labels.clone()
     noised_boxes = known_bboxs.clone()
@@ -64,12 +66,7 @@ def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, lab
             new_label = torch.randint_like(noised_labels, 0, num_classes)
             noised_labels = torch.where(p < (label_noise_ratio * 0.5), new_label, noised_labels)
 
-    single_pad = max_gt
-    pad_size = int(single_pad * 2 * groups)
-    positive_idx = torch.arange(total, device=device).unsqueeze(0).repeat(groups, 1)
-    positive_idx = positive_idx + (torch.arange(groups, device=device) * total * 2).unsqueeze(1)
-    positive_idx = positive_idx.flatten()
-    negative_idx = positive_idx + total
+    negative_idx = static["negative_idx"]
 
     if box_noise_scale > 0:
         corners = torch.zeros_like(known_bboxs)
@@ -97,19 +94,49 @@ def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, lab
     input_query_label = torch.zeros(batch_size, pad_size, hidden_dim, device=device)
     input_query_bbox = torch.zeros(batch_size, pad_size, 4, device=device)
     if total > 0:
+        input_query_label[(known_bid, static["slot"])] = label_embed
+        input_query_bbox[(known_bid, static["slot"])] = bbox_embed
+
+    dn_meta = {"pad_size": pad_size, "num_dn_group": groups}
+    return input_query_label, input_query_bbox, static["attn_mask"], dn_meta
+
+
+_STATIC = {}
+
+
+def _static_parts(counts, groups, num_queries, device):
+    """Index tensors and the attention mask of prepare_for_cdn depend only on the per-image box
+    counts, the number of groups and the number of queries: built once per distinct key (about
+    40 small launches per step otherwise).  The mask is shared between steps: read-only."""
+    key = (counts, groups, num_queries, str(device))
+    parts = _STATIC.get(key)
+    if parts is not None:
+        return parts
+    total, single_pad = sum(counts), (max(counts) if counts else 0)
+    pad_size = int(single_pad * 2 * groups)
+    batch_idx = torch.cat([torch.full((c,), i, dtype=torch.int64, device=device)
+                           for i, c in enumerate(counts)]) if counts else \
+        torch.zeros(0, dtype=torch.int64, device=device)
+    known_bid = batch_idx.repeat(2 * groups, 1).view(-1)
+    positive_idx = torch.arange(total, device=device).unsqueeze(0).repeat(groups, 1)
+    positive_idx = positive_idx + (torch.arange(groups, device=device) * total * 2).unsqueeze(1)
+    negative_idx = positive_idx.flatten() + total
+    if total > 0:
         within = torch.cat([torch.arange(c, device=device) for c in counts])
         slot = torch.cat([within + single_pad * i for i in range(2 * groups)]).long()
-        input_query_label[(known_bid.long(), slot)] = label_embed
-        input_query_bbox[(known_bid.long(), slot)] = bbox_embed
-
+    else:
+        slot = torch.zeros(0, dtype=torch.int64, device=device)
     tgt_size = pad_size + num_queries
     attn_mask = torch.zeros(tgt_size, tgt_size, dtype=torch.bool, device=device)
     attn_mask[pad_size:, :pad_size] = True            # matching queries never see DN queries
     if pad_size > 0:
         gid = torch.arange(pad_size, device=device) // max(2 * single_pad, 1)
         attn_mask[:pad_size, :pad_size] = gid[:, None] != gid[None, :]   # groups are mutually blind
-    dn_meta = {"pad_size": pad_size, "num_dn_group": groups}
-    return input_query_label, input_query_bbox, attn_mask, dn_meta
+    if len(_STATIC) > 64:
+        _STATIC.clear()
+    parts = _STATIC[key] = {"known_bid": known_bid, "negative_idx": negative_idx, "slot": slot,
+                            "attn_mask": attn_mask}
+    return parts
 
 
 def dn_post_process(outputs_class, outputs_coord, dn_meta, aux_loss, _set_aux_loss):

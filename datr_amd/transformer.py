@@ -327,6 +327,16 @@ class TransformerDecoder(nn.Module):
                 spatial_shapes: Optional[Tensor] = None, valid_ratios: Optional[Tensor] = None):
         output = tgt
         intermediate = []
+        if tgt_mask is not None and tgt_mask.dtype == torch.bool:
+            # nn.MultiheadAttention turns a boolean mask into an additive one in every layer
+            # (F._canonical_mask: zeros + masked_fill -inf); do it once, and once per mask object
+            # (prepare_for_cdn hands out the same cached mask every step)
+            cached = getattr(self, "_additive_mask", None)
+            if cached is None or cached[0] is not tgt_mask:
+                cached = (tgt_mask, torch.zeros(tgt_mask.shape, dtype=tgt.dtype, device=tgt_mask.device)
+                          .masked_fill_(tgt_mask, float("-inf")))
+                self._additive_mask = cached
+            tgt_mask = cached[1]
         reference_points = refpoints_unsigmoid.sigmoid()
         ref_points = [reference_points]
         for layer_id, layer in enumerate(self.layers):
