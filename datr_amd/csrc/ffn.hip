@@ -84,6 +84,33 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(
     }
 }
 
+// Column sums of a SHORT matrix (rows <= kSmallRows: the decoder's [4400, 256] gradients) in one
+// launch: a workgroup owns 4 float4 columns, 64 row slices per column (fixed order), LDS tree.
+constexpr int kSmallRows = 8192;
+
+__global__ __launch_bounds__(kThreads) void colsum_small_kernel(
+    const float4 *__restrict__ x, int rows, int cols4, float4 *__restrict__ out)
+{
+    __shared__ float4 red[64][4];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols4) {
+#pragma unroll 4
+        for (int r = sl; r < rows; r += 64) {
+            const float4 v = x[(int64_t)r * cols4 + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < cols4) {
+        float4 t = red[0][cl];
+        for (int i = 1; i < 64; ++i) { t.x += red[i][cl].x; t.y += red[i][cl].y; t.z += red[i][cl].z; t.w += red[i][cl].w; }
+        out[c] = t;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t datr_relu_bwd_bias_partial_rows(int64_t rows) {
@@ -128,6 +155,12 @@ extern "C" int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float
                                                                                      : DATR_ELAUNCH;
     if (!x || !partial) return DATR_EINVAL;
     const int cols4 = (int)(cols / 4);
+    if (rows <= kSmallRows) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((unsigned)((cols4 + 3) / 4)), dim3(kThreads), 0, st,
+                           reinterpret_cast<const float4 *>(x), (int)rows, cols4,
+                           reinterpret_cast<float4 *>(out));
+        return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+    }
     const int nblk = (int)datr_relu_bwd_bias_partial_rows(rows);
     dim3 grid((unsigned)((cols4 + kThreads - 1) / kThreads), (unsigned)nblk);
     hipLaunchKernelGGL(relu_bwd_bias_kernel<false>, grid, dim3(kThreads), 0, st,
