@@ -365,6 +365,8 @@ def main():
         if timer.shape is not None:
             line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
         if world == 1 and not args.no_cpu_baseline:
+            if dist.is_initialized():       # one-rank RCCL mode: the CPU leg must not see a NCCL group
+                dist.destroy_process_group()
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
