@@ -171,6 +171,12 @@ class DINO(nn.Module):
             classes = torch.stack([h(x) for h, x in zip(self.class_embed, hs)])
         return classes, coords
 
+    def side_stream_parameters(self):
+        """Parameters whose gradients are produced on the side stream (the image-level
+        discriminator when OVERLAP_D_IMG): datr_amd.dist.GradAllReducer buckets them apart."""
+        d = getattr(self, "D_img", None)
+        return list(d.parameters()) if (d is not None and OVERLAP_D_IMG) else []
+
     @torch.jit.unused
     def _set_aux_loss(self, outputs_class, outputs_coord):
         return [{"pred_logits": a, "pred_boxes": b}
