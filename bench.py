@@ -84,6 +84,7 @@ class Trainer:
         self.max_norm = self.cfg.clip_max_norm
 
     def step(self, samples, targets):
+        self.criterion.prefetch_num_boxes(targets, samples.tensors.device)
         out = self.model(samples, targets)
         loss_dict = self.criterion(out, targets)
         from datr_amd.criterion import weighted_total

@@ -314,6 +314,19 @@ class SetCriterion(nn.Module):
                 raise AssertionError(f"do you really want to compute {loss} loss?")
         return res
 
+    _nb_prefetch = None
+
+    def prefetch_num_boxes(self, targets, device):
+        """Optional, data parallel only: start the `num_boxes` all-reduce (dino.py:766-767) BEFORE
+        the forward pass -- it depends on the targets alone -- so that the criterion does not stall
+        the compute stream on a collective's latency in the middle of the step.  Every rank must
+        call it (or none); the next forward() with the same box count consumes it."""
+        if not is_dist_avail_and_initialized():
+            return
+        num_boxes = float(sum(len(t["labels"]) for t in targets))
+        nb = torch.full((1,), num_boxes, dtype=torch.float, device=device)
+        self._nb_prefetch = (num_boxes, nb, dist.all_reduce(nb, async_op=True))
+
     def forward(self, outputs, targets, return_indices=False, target_domain_flag=False):
         sfx = "_target" if target_domain_flag else ""
         if target_domain_flag:
@@ -342,10 +355,15 @@ class SetCriterion(nn.Module):
             indices, num_boxes = None, 1.0
 
         if is_dist_avail_and_initialized():
-            # torch.full = a fill kernel with a scalar argument; as_tensor([x], device=...) would be a
-            # pageable host->device copy, i.e. a host synchronisation in every step
-            nb = torch.full((1,), num_boxes, dtype=torch.float, device=device)
-            dist.all_reduce(nb)
+            pre, self._nb_prefetch = self._nb_prefetch, None
+            if pre is not None and indices is not None and pre[0] == num_boxes and pre[1].device == device:
+                pre[2].wait()               # issued before the forward pass: long complete
+                nb = pre[1]
+            else:
+                # torch.full = a fill kernel with a scalar argument; as_tensor([x], device=...) would
+                # be a pageable host->device copy, i.e. a host synchronisation in every step
+                nb = torch.full((1,), num_boxes, dtype=torch.float, device=device)
+                dist.all_reduce(nb)
             if indices is None:
                 nb = nb - 1
             num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]   # stays on device: no sync

@@ -49,6 +49,8 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     for samples, targets, _, _ in data_loader:
         samples = samples.to(device)
         targets = [{k: v.to(device) for k, v in t.items()} for t in targets]
+        if hasattr(criterion, "prefetch_num_boxes"):
+            criterion.prefetch_num_boxes(targets, device)
         with torch.autocast(device_type=device.type, enabled=amp):
             outputs = model(samples, targets) if need_tgt_for_training else model(samples)
             loss_dict = criterion(outputs, targets)
