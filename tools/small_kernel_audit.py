@@ -70,6 +70,27 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fwd, bwd = collections.defaultdict(lambda: [0.0, 0]), collections.defaultdict(lambda: [0.0, 0])
 total = [0.0, 0]
+
+
+def region_of(ev):
+    p = ev.cpu_parent
+    while p is not None:
+        if p.name.startswith("REGION:"):
+            return p.name[7:]
+        p = p.cpu_parent
+    return None
+
+
+# autograd sequence numbers tie a backward node to the forward op that created it
+seq2region = {}
+for ev in prof.events():
+    if ev.device_type.name == "CPU" and getattr(ev, "sequence_nr", -1) is not None \
+            and getattr(ev, "sequence_nr", -1) >= 0 and "evaluate_function" not in ev.name \
+            and "Backward" not in ev.name:
+        r = region_of(ev)
+        if r is not None:
+            seq2region.setdefault(ev.sequence_nr, r)
+bwd_region = collections.defaultdict(lambda: [0.0, 0])
 for ev in prof.events():
     if ev.device_type.name != "CPU" or not getattr(ev, "kernels", None):
         continue
@@ -93,13 +114,21 @@ for ev in prof.events():
         fwd["== " + region][0] += t
         fwd["== " + region][1] += n
     else:
-        p, name = ev.cpu_parent, ev.name
+        p, name, seq = ev.cpu_parent, ev.name, None
         while p is not None:
             if "evaluate_function" in p.name or "Backward" in p.name or "Optimizer" in p.name:
                 name = p.name
+                if getattr(p, "sequence_nr", -1) is not None and getattr(p, "sequence_nr", -1) >= 0:
+                    seq = p.sequence_nr
             p = p.cpu_parent
         bwd[name][0] += t
         bwd[name][1] += n
+        if seq is not None:
+            r = seq2region.get(seq, "(unattributed)")
+            bwd_region[r][0] += t
+            bwd_region[r][1] += n
+            bwd_region[r + " :: " + name.replace("autograd::engine::evaluate_function: ", "")][0] += t
+            bwd_region[r + " :: " + name.replace("autograd::engine::evaluate_function: ", "")][1] += n
 import itertools
 for ev in itertools.islice((e for e in prof.events() if e.stack), 3):
     print("sample stack:", ev.name, ev.stack[:6])
@@ -109,4 +138,7 @@ for k, (t, n) in sorted(fwd.items(), key=lambda x: -x[1][0])[:70]:
     print(f"  {t / 1e3:6.3f} ms {n:4d}  {k[:110]}")
 print("backward / other, by autograd node:")
 for k, (t, n) in sorted(bwd.items(), key=lambda x: -x[1][0])[:40]:
+    print(f"  {t / 1e3:6.3f} ms {n:4d}  {k[:110]}")
+print("backward, by the forward region that created the node:")
+for k, (t, n) in sorted(bwd_region.items(), key=lambda x: -x[1][0])[:60]:
     print(f"  {t / 1e3:6.3f} ms {n:4d}  {k[:110]}")
