@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .fused import FastLinear
+from .fused import linear as fused_linear
 from .msda import MSDeformAttn
 from .nested import inverse_sigmoid
 
@@ -55,6 +56,39 @@ def _add_norm(x, branch, dropout, norm):
 
 
 FUSED_FFN = __import__("os").environ.get("DATR_FUSED_FFN", "1") != "0"     # A/B switch
+FUSED_SELF_ATTN = __import__("os").environ.get("DATR_FUSED_SELF_ATTN", "1") != "0"   # A/B switch
+
+
+def _plain_mha(m: nn.MultiheadAttention) -> bool:
+    return (m._qkv_same_embed_dim and m.in_proj_bias is not None and not m.batch_first
+            and m.bias_k is None and not m.add_zero_attn and not (m.training and m.dropout > 0))
+
+
+def _self_attention(mha: nn.MultiheadAttention, qk_in: Tensor, v_in: Tensor, attn_mask) -> Tensor:
+    """`mha(qk_in, qk_in, v_in, attn_mask=attn_mask, need_weights=False)[0]` for [L, N, E] inputs --
+    the decoder's self-attention call (deformable_transformer.py:880-884: query = key = tgt + pos,
+    value = tgt) -- with the same parameters and the same operations per element, arranged for
+    fewer launches: the query and key projections share their input, so they are ONE GEMM
+    (nn.MultiheadAttention runs three because value differs); linears go through fused.linear
+    (column-sum bias gradients); the in_proj parameters are split, not sliced (one backward
+    node).  Scaled dot-product attention itself is PyTorch's kernel."""
+    L, N, E = qk_in.shape
+    H = mha.num_heads
+    hd = E // H
+    w_qk, w_v = mha.in_proj_weight.split([2 * E, E], 0)
+    b_qk, b_v = mha.in_proj_bias.split([2 * E, E], 0)
+    q, k = fused_linear(qk_in, w_qk, b_qk).split(E, dim=-1)              # [L, N, E] views
+    v = fused_linear(v_in, w_v, b_v)
+    # [L, N, E] -> [N, H, L, hd] (views, as F.multi_head_attention_forward arranges them)
+    q, k, v = (x.reshape(L, N * H, hd).transpose(0, 1).reshape(N, H, L, hd) for x in (q, k, v))
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            attn_mask = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device) \
+                .masked_fill_(attn_mask, float("-inf"))
+        attn_mask = attn_mask.view(1, 1, L, L)
+    out = F.scaled_dot_product_attention(q, k, v, attn_mask, 0.0, False)     # [N, H, L, hd]
+    out = out.permute(2, 0, 1, 3).reshape(L * N, E)
+    return fused_linear(out, mha.out_proj.weight, mha.out_proj.bias).view(L, N, E)
 
 
 def _ffn(x, linear1, activation, dropout, linear2):
@@ -266,7 +300,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_sa(self, tgt, query_pos, attn_mask):
         q = k = tgt if query_pos is None else tgt + query_pos
-        tgt2 = self.self_attn(q, k, tgt, attn_mask=attn_mask, need_weights=False)[0]
+        if FUSED_SELF_ATTN and tgt.is_cuda and _plain_mha(self.self_attn):
+            tgt2 = _self_attention(self.self_attn, q, tgt, attn_mask)
+        else:
+            tgt2 = self.self_attn(q, k, tgt, attn_mask=attn_mask, need_weights=False)[0]
         return _add_norm(tgt, tgt2, self.dropout2, self.norm2)
 
     def forward_ca(self, tgt, query_pos, reference_points, memory, spatial_shapes,

@@ -277,3 +277,35 @@ def test_cached_proposals_equal_uncached():
     for _ in range(2):                                     # second call hits the cache
         m1, p1 = gen_encoder_output_proposals(mem, mask, shapes, no_padding=True)
         assert torch.equal(m0, m1) and torch.equal(p0, p1)
+
+
+def test_decoder_self_attention_matches_nn_multihead_attention():
+    """transformer._self_attention (merged q/k projection) against nn.MultiheadAttention with
+    query = key = tgt + pos, value = tgt and the DN attention mask: outputs and every gradient."""
+    from datr_amd.transformer import _plain_mha, _self_attention
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    L, N, E = 300, 3, 256
+    mha = torch.nn.MultiheadAttention(E, 8, dropout=0.0).to(dev)
+    assert _plain_mha(mha)
+    tgt = torch.randn(L, N, E, device=dev)
+    pos = torch.randn(L, N, E, device=dev)
+    mask = torch.zeros(L, L, dtype=torch.bool, device=dev)
+    mask[100:, :100] = True
+    mask[:50, 50:100] = True
+    mask[50:100, :50] = True
+    go = torch.randn(L, N, E, device=dev)
+    outs, grads = [], []
+    for fused_path in (True, False):
+        t = tgt.clone().requires_grad_(True)
+        p = pos.clone().requires_grad_(True)
+        mha.zero_grad()
+        q = t + p
+        y = (_self_attention(mha, q, t, mask) if fused_path
+             else mha(q, q, t, attn_mask=mask, need_weights=False)[0])
+        y.backward(go)
+        outs.append(y.detach())
+        grads.append([t.grad, p.grad] + [x.grad.clone() for x in mha.parameters()])
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-4, atol=1e-5)
+    for a, b in zip(*grads):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
