@@ -1,6 +1,8 @@
 """Small fused element-wise ops backed by libdatr_hip.so."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -315,3 +317,67 @@ def conv3x3_lrelu_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
             _native.current_stream_ptr(x.device))
     _native.check(rc, "conv3x3_nhwc_forward")
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# Scaled-dot-product attention, head_dim 32: own MFMA forward (csrc/mha_fwd.hip), PyTorch's
+# memory-efficient backward fed with the own (out, log-sum-exp).
+# ---------------------------------------------------------------------------------------------
+_PHILOX = {}
+
+
+def _philox_placeholders(device):
+    """The (seed, offset) tensors PyTorch's efficient-attention backward wants; unused at
+    dropout 0 -- taken once from a tiny forward call so that dtype / device are whatever this
+    build expects."""
+    if device not in _PHILOX:
+        z = torch.zeros(1, 1, 32, 32, device=device)
+        res = torch.ops.aten._scaled_dot_product_efficient_attention(z, z, z, None, True, 0.0, False)
+        _PHILOX[device] = (res[2], res[3])
+    return _PHILOX[device]
+
+
+class _AttentionD32(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, heads):
+        L, N, E = q.shape
+        out = torch.empty(L, N, E, device=q.device, dtype=torch.float32)
+        lse = torch.empty(N, heads, L, device=q.device, dtype=torch.float32)
+        strides = (ctypes.c_int64 * 8)(q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                       v.stride(0), v.stride(1), out.stride(0), out.stride(1))
+        with torch.cuda.device(q.device):
+            rc = _native.lib.datr_mha_forward_d32_f32(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), 0 if mask is None else mask.data_ptr(), L, N,
+                heads, ctypes.addressof(strides), 32 ** -0.5, out.data_ptr(), lse.data_ptr(),
+                _native.current_stream_ptr(q.device))
+        _native.check(rc, "mha_forward_d32")
+        ctx.save_for_backward(q, k, v, out, lse, mask)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v, out, lse, mask = ctx.saved_tensors
+        L, N, E = q.shape
+        H = ctx.heads
+        to4 = lambda x: x.reshape(L, N, H, 32).permute(1, 2, 0, 3)           # [N, H, L, 32] views
+        bias = None if mask is None else mask.view(1, 1, L, L).expand(N, H, L, L)
+        seed, offset = _philox_placeholders(q.device)
+        dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
+            to4(dout.contiguous()), to4(q), to4(k), to4(v), bias, to4(out), lse, seed, offset, 0.0,
+            [True, True, True, False], False)
+        back = lambda g: g.permute(2, 0, 1, 3).reshape(L, N, E)
+        return back(dq), back(dk), back(dv), None, None
+
+
+def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask, heads: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(32) + mask) v per (batch, head) for sequence-first [L, N, heads * 32]
+    device float32 tensors (last dim contiguous, other strides multiples of 4 -- column slices of a
+    merged projection are fine); mask: additive float [L, L] or None.  Returns [L, N, heads * 32]
+    contiguous, i.e. what nn.MultiheadAttention hands to out_proj."""
+    assert q.is_cuda and q.dtype == torch.float32 and q.shape == k.shape == v.shape
+    assert q.shape[-1] == heads * 32 and q.stride(-1) == k.stride(-1) == v.stride(-1) == 1
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.shape == (q.shape[0], q.shape[0]) and mask.is_contiguous()
+    return _AttentionD32.apply(q, k, v, mask, heads)

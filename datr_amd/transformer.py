@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .fused import FastLinear
+from .fused import attention_d32
 from .fused import linear as fused_linear
 from .msda import MSDeformAttn
 from .nested import inverse_sigmoid
@@ -57,6 +58,7 @@ def _add_norm(x, branch, dropout, norm):
 
 FUSED_FFN = __import__("os").environ.get("DATR_FUSED_FFN", "1") != "0"     # A/B switch
 FUSED_SELF_ATTN = __import__("os").environ.get("DATR_FUSED_SELF_ATTN", "1") != "0"   # A/B switch
+OWN_ATTENTION = __import__("os").environ.get("DATR_OWN_ATTENTION", "1") != "0"       # A/B switch
 
 
 def _plain_mha(m: nn.MultiheadAttention) -> bool:
@@ -79,15 +81,20 @@ def _self_attention(mha: nn.MultiheadAttention, qk_in: Tensor, v_in: Tensor, att
     b_qk, b_v = mha.in_proj_bias.split([2 * E, E], 0)
     q, k = fused_linear(qk_in, w_qk, b_qk).split(E, dim=-1)              # [L, N, E] views
     v = fused_linear(v_in, w_v, b_v)
-    # [L, N, E] -> [N, H, L, hd] (views, as F.multi_head_attention_forward arranges them)
-    q, k, v = (x.reshape(L, N * H, hd).transpose(0, 1).reshape(N, H, L, hd) for x in (q, k, v))
-    if attn_mask is not None:
-        if attn_mask.dtype == torch.bool:
-            attn_mask = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device) \
-                .masked_fill_(attn_mask, float("-inf"))
-        attn_mask = attn_mask.view(1, 1, L, L)
-    out = F.scaled_dot_product_attention(q, k, v, attn_mask, 0.0, False)     # [N, H, L, hd]
-    out = out.permute(2, 0, 1, 3).reshape(L * N, E)
+    if attn_mask is not None and attn_mask.dtype == torch.bool:
+        attn_mask = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device) \
+            .masked_fill_(attn_mask, float("-inf"))
+    if OWN_ATTENTION and hd == 32 and q.dtype == torch.float32 and all(
+            x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0 for x in (q, k, v)):
+        # own MFMA forward (csrc/mha_fwd.hip), output already in the [L, N, E] layout out_proj reads
+        out = attention_d32(q, k, v, None if attn_mask is None else attn_mask.contiguous(), H)
+        out = out.view(L * N, E)
+    else:
+        # [L, N, E] -> [N, H, L, hd] (views, as F.multi_head_attention_forward arranges them)
+        q, k, v = (x.reshape(L, N * H, hd).transpose(0, 1).reshape(N, H, L, hd) for x in (q, k, v))
+        out = F.scaled_dot_product_attention(
+            q, k, v, None if attn_mask is None else attn_mask.view(1, 1, L, L), 0.0, False)
+        out = out.permute(2, 0, 1, 3).reshape(L * N, E)
     return fused_linear(out, mha.out_proj.weight, mha.out_proj.bias).view(L, N, E)
 
 

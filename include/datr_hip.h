@@ -195,6 +195,18 @@ int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial, 
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention forward, head_dim 32, additive [L, L] mask (may be
+ * NULL), exact fp32 on the MFMA units: out = softmax(scale * Q K^T + mask) V per (batch n, head h) --
+ * the decoder's self-attention (nn.MultiheadAttention in
+ * /root/reference/models/dino/deformable_transformer.py:880-884).  Element (l, n, h, d) of a
+ * tensor x is x[l * ld_l + n * ld_n + h * 32 + d]; strides = {q_l, q_n, k_l, k_n, v_l, v_n, o_l, o_n}
+ * in floats, all multiples of 4.  lse [N, H, L] (natural log of the softmax denominator plus the
+ * row maximum) may be NULL. */
+int datr_mha_forward_d32_f32(const float *q, const float *k, const float *v, const float *mask,
+                             int64_t L, int64_t N, int64_t H, const int64_t *strides, float scale,
+                             float *out, float *lse, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Cost matrix of the Hungarian matcher (/root/reference/models/dino/matcher.py:48-88) for `sets`
  * = (prediction sets x images) blocks of nq queries against all T ground-truth boxes of the
  * batch: logits [sets * nq, C], boxes [sets * nq, 4] cxcywh, tgt_ids [T] int64, tgt_boxes [T, 4].

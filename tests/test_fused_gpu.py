@@ -279,13 +279,14 @@ def test_cached_proposals_equal_uncached():
         assert torch.equal(m0, m1) and torch.equal(p0, p1)
 
 
-def test_decoder_self_attention_matches_nn_multihead_attention():
+@pytest.mark.parametrize("L", [300, 301, 1100])
+def test_decoder_self_attention_matches_nn_multihead_attention(L):
     """transformer._self_attention (merged q/k projection) against nn.MultiheadAttention with
     query = key = tgt + pos, value = tgt and the DN attention mask: outputs and every gradient."""
     from datr_amd.transformer import _plain_mha, _self_attention
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
-    L, N, E = 300, 3, 256
+    N, E = 3, 256
     mha = torch.nn.MultiheadAttention(E, 8, dropout=0.0).to(dev)
     assert _plain_mha(mha)
     tgt = torch.randn(L, N, E, device=dev)
