@@ -29,13 +29,27 @@ def main():
         samples, targets = bench.synthetic_batch(b, size[0], size[1], gt, dev, seed=1)
         for _ in range(2):
             tr.step(samples, targets)
+        # the eval-mode forward of the teacher / the evaluation loop (target half only: other M)
+        tr.model.eval()
+        with torch.no_grad():
+            half = samples.tensors.shape[0] // 2
+            tr.model(samples.tensors[half:].contiguous())
+        tr.model.train()
     torch.cuda.synchronize()
+    results = {(op, params): (solution, ms) for op, params, solution, ms in t.get_results()}
+    kept = 0
+    if os.path.exists(tuning.RESULTS):          # shapes not seen in this run keep their selection
+        for line in open(tuning.RESULTS):
+            p = line.rstrip("\n").split(",")
+            if len(p) >= 4 and p[0] != "Validator" and (p[0], p[1]) not in results:
+                results[(p[0], p[1])] = (p[2], p[3])
+                kept += 1
     with open(tuning.RESULTS, "w") as f:        # same layout TunableOp itself writes at exit
         for key, val in t.get_validators():
             f.write(f"Validator,{key},{val}\n")
-        for op, params, solution, ms in t.get_results():
+        for (op, params), (solution, ms) in results.items():
             f.write(f"{op},{params},{solution},{ms}\n")
-    print("wrote", tuning.RESULTS, "with", len(t.get_results()), "entries")
+    print("wrote", tuning.RESULTS, "with", len(results), "entries,", kept, "kept from the previous file")
 
 
 if __name__ == "__main__":
