@@ -39,6 +39,8 @@ _SIGNATURES = {
     "datr_lsap_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "datr_colsum_f32": [_vp, _i64, _i64, _vp, _vp, _vp],
     "datr_wgrad_k256_f32": [_vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "datr_msda_prologue_forward_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "datr_msda_prologue_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "datr_mha_forward_d32_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_float, _vp, _vp, _vp],
     "datr_match_cost_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
                             ctypes.c_float, ctypes.c_float, _vp, _vp, _vp],

@@ -191,6 +191,44 @@ class _SplitLast(Function):
         return torch.cat([ga, gb], -1), None
 
 
+class _Prologue(Function):
+    """(sampling locations, attention weights) from the merged query projection in one launch
+    each way (csrc/msda_prologue.hip); 8 heads x 4 levels x 4 points, reference points without
+    gradient."""
+
+    @staticmethod
+    def forward(ctx, both, ref):
+        rows = both.numel() // 384
+        both, ref = both.contiguous(), ref.contiguous()
+        loc = torch.empty(*both.shape[:-1], 8, 4, 4, 2, device=both.device, dtype=torch.float32)
+        attn = torch.empty(*both.shape[:-1], 8, 4, 4, device=both.device, dtype=torch.float32)
+        with torch.cuda.device(both.device):
+            rc = _native.lib.datr_msda_prologue_forward_f32(
+                both.data_ptr(), ref.data_ptr(), rows, ref.shape[-1], loc.data_ptr(), attn.data_ptr(),
+                _native.current_stream_ptr(both.device))
+        _native.check(rc, "msda_prologue_forward")
+        ctx.save_for_backward(attn, ref)
+        ctx.shape = both.shape
+        return loc, attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_loc, d_attn):
+        attn, ref = ctx.saved_tensors
+        d_loc = torch.zeros_like(attn).unsqueeze(-1).expand(*attn.shape, 2).contiguous() \
+            if d_loc is None else d_loc.contiguous()
+        d_attn = torch.zeros_like(attn) if d_attn is None else d_attn.contiguous()
+        d_both = torch.empty(ctx.shape, device=attn.device, dtype=torch.float32)
+        with torch.cuda.device(attn.device):
+            rc = _native.lib.datr_msda_prologue_backward_f32(
+                d_loc.data_ptr(), d_attn.data_ptr(), attn.data_ptr(), ref.data_ptr(),
+                d_both.numel() // 384, ref.shape[-1], d_both.data_ptr(),
+                _native.current_stream_ptr(attn.device))
+        _native.check(rc, "msda_prologue_backward")
+        return d_both, None
+
+
+FUSED_PROLOGUE = __import__("os").environ.get("DATR_FUSED_PROLOGUE", "1") != "0"      # A/B switch
 _INV_WH = {}
 
 
@@ -276,6 +314,14 @@ class MSDeformAttn(nn.Module):
             w = torch.cat([w_off, self.attention_weights.weight], 0)
             b = torch.cat([b_off, self.attention_weights.bias], 0)
             both = fast_linear(query, w, b)
+            if FUSED_PROLOGUE and (H, self.n_levels, self.n_points) == (8, 4, 4) \
+                    and both.dtype == torch.float32 and not reference_points.requires_grad \
+                    and reference_points.shape[-1] in (2, 4) \
+                    and (fold_wh or reference_points.shape[-1] == 4) and value.dtype == torch.float32:
+                locations, weights = _Prologue.apply(both, reference_points.float())
+                out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                                 locations, weights, self.im2col_step)
+                return self.output_proj(out)
             n_off = self.sampling_offsets.out_features
             off2, wts2 = _SplitLast.apply(both, n_off)
             offsets = off2.view(N, Len_q, H, self.n_levels, self.n_points, 2)

@@ -195,6 +195,20 @@ int datr_colsum_f32(const float *x, int64_t rows, int64_t cols, float *partial, 
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sampling locations and attention weights of MSDeformAttn (8 heads, 4 levels, 4 points) from the
+ * merged query projection (/root/reference/models/dino/ops/modules/ms_deform_attn.py:96-117):
+ * both [rows, 384] = (256 sampling offsets in (head, level, point, xy) order | 128 logits),
+ * ref [rows, 4, ref_dim] reference points (ref_dim 2: loc = ref + offset, offsets already divided
+ * by (W_l, H_l); ref_dim 4: loc = ref_xy + offset / 4 * ref_wh * 0.5), loc [rows, 8, 4, 4, 2],
+ * attn [rows, 8, 16] = softmax over (level, point).  backward: d_both [rows, 384] from d_loc,
+ * d_attn and the saved attn; the reference points get no gradient. */
+int datr_msda_prologue_forward_f32(const float *both, const float *ref, int64_t rows, int64_t ref_dim,
+                                   float *loc, float *attn, void *stream);
+int datr_msda_prologue_backward_f32(const float *d_loc, const float *d_attn, const float *attn,
+                                    const float *ref, int64_t rows, int64_t ref_dim, float *d_both,
+                                    void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Scaled-dot-product attention forward, head_dim 32, additive [L, L] mask (may be
  * NULL), exact fp32 on the MFMA units: out = softmax(scale * Q K^T + mask) V per (batch n, head h) --
  * the decoder's self-attention (nn.MultiheadAttention in

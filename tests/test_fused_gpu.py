@@ -310,3 +310,44 @@ def test_decoder_self_attention_matches_nn_multihead_attention(L):
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-4, atol=1e-5)
     for a, b in zip(*grads):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("ref_dim,Lq", [(2, 701), (4, 300)])
+def test_fused_sampling_prologue_matches_torch_ops(ref_dim, Lq):
+    """csrc/msda_prologue.hip (softmax + sampling locations from the merged query projection,
+    forward and backward) against the torch op sequence of MSDeformAttn.forward
+    (ms_deform_attn.py:96-117) inside the whole module: output and all gradients."""
+    from datr_amd import msda
+    dev = torch.device("cuda:0")
+    torch.manual_seed(ref_dim)
+    shapes = [(20, 27), (10, 14), (5, 7), (3, 4)]
+    S = sum(h * w for h, w in shapes)
+    spatial = torch.tensor(shapes, dtype=torch.int64, device=dev)
+    lsi = torch.cat([spatial.new_zeros(1), (spatial[:, 0] * spatial[:, 1]).cumsum(0)[:-1]])
+    mod = msda.MSDeformAttn(256, 4, 8, 4).to(dev)
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.05)
+    N = 2
+    if ref_dim == 2:
+        Lq = S
+    query = torch.randn(N, Lq, 256, device=dev)
+    src = torch.randn(N, S, 256, device=dev)
+    ref = torch.rand(N, Lq, 4, ref_dim, device=dev) * 0.8 + 0.1
+    if ref_dim == 4:
+        ref[..., 2:] *= 0.3
+    go = torch.randn(N, Lq, 256, device=dev)
+    res = []
+    for fused_path in (True, False):
+        msda.FUSED_PROLOGUE = fused_path
+        try:
+            q = query.clone().requires_grad_(True)
+            x = src.clone().requires_grad_(True)
+            mod.zero_grad()
+            y = mod(q, ref, x, spatial, lsi, None)
+            y.backward(go)
+            res.append([y.detach(), q.grad, x.grad] + [p.grad.clone() for p in mod.parameters()])
+        finally:
+            msda.FUSED_PROLOGUE = True
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
