@@ -66,9 +66,14 @@ __global__ __launch_bounds__(256) void prologue_fwd(const float *__restrict__ bo
                          c.x + o1.z / kP * c.z * 0.5f, c.y + o1.w / kP * c.w * 0.5f);
     }
     if (ok) {
-        *reinterpret_cast<float4 *>(loc + i * 8) = a0;
-        *reinterpret_cast<float4 *>(loc + i * 8 + 4) = a1;
-        *reinterpret_cast<float4 *>(attn + i * 4) = make_float4(e.x * inv, e.y * inv, e.z * inv, e.w * inv);
+        // streamed once by the MSDA kernel that follows: non-temporal, so that they do not push the
+        // value tensor (gathered ~16 times per element) out of L2 / the infinity cache
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v0 = {a0.x, a0.y, a0.z, a0.w}, v1 = {a1.x, a1.y, a1.z, a1.w};
+        const f4 v2 = {e.x * inv, e.y * inv, e.z * inv, e.w * inv};
+        __builtin_nontemporal_store(v0, reinterpret_cast<f4 *>(loc + i * 8));
+        __builtin_nontemporal_store(v1, reinterpret_cast<f4 *>(loc + i * 8 + 4));
+        __builtin_nontemporal_store(v2, reinterpret_cast<f4 *>(attn + i * 4));
     }
 }
 
