@@ -180,8 +180,10 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_rows(
         acc.w += w.x * v0.w + w.y * v1.w + w.z * v2.w + w.w * v3.w;
     }
     if (live) {
-        float4 *dst = reinterpret_cast<float4 *>(out + (((size_t)n * Lq + q) * M + m) * D) + j;
-        *dst = acc;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 *dst = reinterpret_cast<f4 *>(out + (((size_t)n * Lq + q) * M + m) * D) + j;
+        const f4 r = {acc.x, acc.y, acc.z, acc.w};
+        __builtin_nontemporal_store(r, dst);
     }
 }
 
