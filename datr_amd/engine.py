@@ -18,6 +18,23 @@ from .criterion import weighted_total
 from .nested import reduce_dict
 
 
+def _losses_to_host(loss_dict_reduced, weight_dict):
+    """({key: loss * weight} for weighted keys, {key: loss}) as python floats with ONE
+    device->host transfer (the reference calls .item() / float() per entry: ~170 synchronising
+    copies per step)."""
+    keys = list(loss_dict_reduced)
+    if not keys:
+        return {}, {}
+    vals = [loss_dict_reduced[k] for k in keys]
+    if all(torch.is_tensor(v) for v in vals):
+        host = torch.stack([v.detach().float().reshape(()) for v in vals]).tolist()
+    else:
+        host = [float(v) for v in vals]
+    unscaled = dict(zip(keys, host))
+    scaled = {k: v * float(weight_dict[k]) for k, v in unscaled.items() if k in weight_dict}
+    return scaled, unscaled
+
+
 def _backward_and_step(model, optimizer, losses, max_norm, scaler, amp):
     optimizer.zero_grad()
     if amp:
@@ -58,8 +75,8 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             losses = weighted_total(loss_dict, weight_dict)
 
         loss_dict_reduced = {k: v.detach() for k, v in reduce_dict(loss_dict).items()}
-        scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
-        loss_value = sum(scaled.values()).item()
+        scaled, unscaled = _losses_to_host(loss_dict_reduced, weight_dict)
+        loss_value = sum(scaled.values())
         if not math.isfinite(loss_value):
             print(f"Loss is {loss_value}, stopping training")
             print(loss_dict_reduced)
@@ -84,10 +101,10 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             ema_m.update(model)
 
         stats = {"loss": loss_value, "lr": optimizer.param_groups[0]["lr"]}
-        stats.update({k: float(v) for k, v in scaled.items()})
-        stats.update({f"{k}_unscaled": float(v) for k, v in loss_dict_reduced.items()})
-        if "class_error" in loss_dict_reduced:
-            stats["class_error"] = float(loss_dict_reduced["class_error"])
+        stats.update(scaled)
+        stats.update({f"{k}_unscaled": v for k, v in unscaled.items()})
+        if "class_error" in unscaled:
+            stats["class_error"] = unscaled["class_error"]
         for k, v in stats.items():
             sums[k] += v
             counts[k] += 1
@@ -167,8 +184,8 @@ def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loa
             losses = losses_source + losses_target * weight_dict["loss_self_training"]
 
         loss_dict_reduced = reduce_dict(loss_dict_source)
-        scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
-        loss_value = sum(scaled.values()).item()
+        scaled, unscaled = _losses_to_host(loss_dict_reduced, weight_dict)
+        loss_value = sum(scaled.values())
         if not math.isfinite(loss_value):
             print(f"Loss is {loss_value}, stopping training")
             print(loss_dict_reduced)
@@ -181,15 +198,15 @@ def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loa
         stats = {"loss": loss_value, "lr": optimizer.param_groups[0]["lr"],
                  "loss_self_training_sum": float(losses_target.detach()),
                  "num_pseudo_images": float(len(idx_list))}
-        stats.update({k: float(v) for k, v in scaled.items()})
-        stats.update({f"{k}_unscaled": float(v) for k, v in loss_dict_reduced.items()})
-        if "class_error" in loss_dict_reduced:
-            stats["class_error"] = float(loss_dict_reduced["class_error"])
+        stats.update(scaled)
+        stats.update({f"{k}_unscaled": v for k, v in unscaled.items()})
+        if "class_error" in unscaled:
+            stats["class_error"] = unscaled["class_error"]
         for k, v in stats.items():
             sums[k] += v
             counts[k] += 1
         last = dict(stats, total_loss=float(losses.detach()),
-                    target_loss_dict={k: float(v.detach()) for k, v in loss_dict_target.items()},
+                    target_loss_dict=_losses_to_host(loss_dict_target, {})[1],
                     pseudo_targets=pseudo_list)
         steps += 1
         if getattr(args, "debug", False) and steps % 15 == 0:
