@@ -77,6 +77,10 @@ class GradAllReducer:
                  process_group=None, side_params=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # RCCL averages inside the collective (no division pass over the buckets afterwards); gloo
+        # has no AVG: sum, then divide in finish()
+        nccl = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self._op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
         params = [p for p in model.parameters() if p.requires_grad]
         assert params, "no trainable parameters"
         device, dtype = params[0].device, params[0].dtype
@@ -166,7 +170,7 @@ class GradAllReducer:
                 foreign = cur
         self._gather(b, foreign)
         if collective:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.work = dist.all_reduce(b.flat, op=self._op, group=self.group, async_op=True)
         elif b.flat.is_cuda and cur != torch.cuda.default_stream(dev):
             b.event = cur.record_event()
 
@@ -197,7 +201,7 @@ class GradAllReducer:
             if b.event is not None:
                 torch.cuda.current_stream(b.flat.device).wait_event(b.event)
                 b.event = None
-            if self.world > 1:
+            if self.world > 1 and self._op == dist.ReduceOp.SUM:
                 b.flat.div_(self.world)
 
     def remove(self):
