@@ -4,13 +4,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = the body of the reference's training loop (/root/reference/engine.py:54-111) on
-one synthetic batch: model(samples, targets) -> criterion -> sum(loss*weight) -> zero_grad ->
-backward -> gradient all-reduce -> clip_grad_norm_(0.1) -> AdamW step, for DINO-4scale R50 with
+One "step" = one iteration of `datr_amd.engine.train_one_epoch` -- the counterpart of the
+reference's training loop (/root/reference/engine.py:54-111) -- on one synthetic batch:
+model(samples, targets) -> criterion -> sum(loss*weight) -> reduce_dict for logging -> zero_grad ->
+backward -> gradient all-reduce -> clip_grad_norm_(0.1) -> AdamW step -> loss dict to the host +
+non-finite guard, for DINO-4scale R50 with
 DATR's domain-adaptation branch (the reference has no switch that turns it off while training,
 SURVEY.md 8d), batch_size 2 per GPU = 2 source + 2 target images of 1333x800, fp32.
 Inputs are resident in HBM before the timed region.  Weak scaling: every rank runs the same
-per-GPU batch; value = images of all ranks / max-over-ranks time.
+per-GPU batch; value = images of all ranks / max-over-ranks time.  `--gpus N` with N > 1 started
+as a plain `python bench.py` re-launches itself under torch.distributed.run with N ranks.
 
 Rank 0 prints ONE JSON line: the driver's contract fields plus
   roofline     -- MSDA forward (encoder call, the dominant HIP kernel family of this repo):
@@ -39,67 +42,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
 
 
-def synthetic_batch(batch_size, height, width, num_gt, device, seed):
-    """images randn [2B,3,H,W] (already 'normalised'), no padding; per source
-    image `num_gt` boxes, labels in 1..8, cxcy ~ U(0.2,0.8), wh ~ U(0.05,0.25)."""
-    from datr_amd.nested import NestedTensor
-    g = torch.Generator().manual_seed(seed)
-    imgs = torch.randn(2 * batch_size, 3, height, width, generator=g)
-    mask = torch.zeros(2 * batch_size, height, width, dtype=torch.bool)
-    targets = []
-    for _ in range(batch_size):
-        cxcy = torch.rand(num_gt, 2, generator=g) * 0.6 + 0.2
-        wh = torch.rand(num_gt, 2, generator=g) * 0.2 + 0.05
-        targets.append({"boxes": torch.cat([cxcy, wh], 1).to(device),
-                        "labels": torch.randint(1, 9, (num_gt,), generator=g).to(device)})
-    # equal-size images: no padded pixel, which the collate function would have recorded
-    # (datr_amd.nested.nested_tensor_from_tensor_list sets `padded` from the image sizes)
-    return NestedTensor(imgs.to(device), mask.to(device), padded=False), targets
-
-
-class Trainer:
-    """The per-step sequence of engine.train_one_epoch, with gradients living in the flat
-    buckets of datr_amd.dist.GradAllReducer."""
-
-    def __init__(self, args, device, distributed):
-        from datr_amd.config import c2f_args, get_param_dict
-        from datr_amd.detector import build_dino
-        from datr_amd.dist import GradAllReducer
-        self.cfg = c2f_args(device=str(device))
-        if getattr(args, "tuned_gemm", True):
-            from datr_amd import tuning
-            tuning.enable()          # per-shape hipBLASLt kernel selection, lookup only
-        torch.manual_seed(0)
-        self.model, self.criterion, _ = build_dino(self.cfg)
-        self.model.to(device)
-        if getattr(args, "channels_last", True):
-            self.model.backbone.to(memory_format=torch.channels_last)
-        self.model.train()
-        self.criterion.train()
-        # same update rule as the reference's AdamW (main.py:162-165); `fused` only selects
-        # PyTorch's single-kernel multi-tensor implementation of it
-        self.optimizer = torch.optim.AdamW(get_param_dict(self.cfg, self.model), lr=self.cfg.lr,
-                                           weight_decay=self.cfg.weight_decay, fused=True)
-        self.reducer = GradAllReducer(self.model) if distributed or args.flat_grads else None
-        self.max_norm = self.cfg.clip_max_norm
-
-    def step(self, samples, targets):
-        self.criterion.prefetch_num_boxes(targets, samples.tensors.device)
-        out = self.model(samples, targets)
-        loss_dict = self.criterion(out, targets)
-        from datr_amd.criterion import weighted_total
-        loss = weighted_total(loss_dict, self.criterion.weight_dict)
-        if self.reducer is not None:
-            self.reducer.zero_grad()
-        else:
-            self.optimizer.zero_grad()
-        loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        if self.max_norm > 0:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
-        self.optimizer.step()
-        return loss
+from datr_amd.training import build_training, run_steps, synthetic_batch  # noqa: E402
 
 
 class MsdaTimer:
@@ -177,7 +120,6 @@ def teacher_student_stage(args, device):
     optimizer = torch.optim.AdamW(get_param_dict(cfg, model), lr=cfg.lr, weight_decay=cfg.weight_decay,
                                   fused=True)
     samples, targets = synthetic_batch(args.batch, args.height, args.width, args.num_gt, device, seed=1)
-    samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
     g = torch.Generator().manual_seed(7)
     strong = NestedTensor((samples.tensors + 0.3 * torch.randn(samples.tensors.shape, generator=g).to(device))
                           .contiguous(memory_format=torch.channels_last), samples.mask, padded=False)
@@ -240,9 +182,46 @@ def mfma_utilisation(device, rows):
             "per_gemm_tflops": out}
 
 
-def cpu_baseline():
+def msda_cpu_ops(gpu_us=None):
+    """SURVEY.md 8d 'CPU baseline beside it': the MSDA op at the encoder shape (N=2, 1333x800:
+    S = Lq = 22 223, M=8, D=32, L=P=4) on the host cores -- the C restatement (oracle/msda_ref.c,
+    OpenMP) and the torch `grid_sample` formulation the reference's own CPU path uses
+    (ms_deform_attn_func.py:41-61) -- min of 3 after one warm-up call."""
+    from oracle import msda_oracle as O
+    shapes = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes)
+    value, sh, lsi, loc, attn = O.random_inputs(2, S, 8, 32, shapes, 4, seed=3)
+    go = torch.randn(2, S, 256, generator=torch.Generator().manual_seed(1))
+
+    def best(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return round(min(ts) * 1e3, 1)
+
+    def gs_bwd():
+        v, l_, a = (x.clone().requires_grad_(True) for x in (value, loc, attn))
+        O.msda_grid_sample(v, sh, l_, a).backward(go)
+    out = {"shape": "N=2 S=Lq=22223 M=8 D=32 L=P=4 (encoder call)",
+           "oracle_c_fwd_ms": best(lambda: O.msda_forward(value, sh, lsi, loc, attn)),
+           "oracle_c_bwd_ms": best(lambda: O.msda_backward(value, sh, lsi, loc, attn, go)),
+           "grid_sample_fwd_ms": best(lambda: O.msda_grid_sample(value, sh, loc, attn)),
+           "grid_sample_fwd_bwd_ms": best(gs_bwd, reps=2),
+           "threads": torch.get_num_threads()}
+    if gpu_us is not None:
+        out["hip_fwd_ms_same_shape"] = round(gpu_us / 1e3, 4)
+    return out
+
+
+def cpu_baseline(msda_gpu_us=None):
     """Reference-equivalent CPU step (torch CPU kernels + the oracle for MSDA / focal loss) on the host
-    cores: ONE training step at 640x640, B=1 (2 images), after one un-timed build."""
+    cores: ONE timed training step at 640x640, B=1 (2 images) after one un-timed warm-up step --
+    BASELINE config 1's shape; like every training step of the reference it includes the
+    domain-adaptation branch (there is no switch that turns it off).  Plus the MSDA
+    op alone at the encoder shape (`msda_cpu_ops`)."""
     from datr_amd import msda
     from datr_amd.config import c2f_args, get_param_dict
     from datr_amd.detector import build_dino
@@ -267,22 +246,45 @@ def cpu_baseline():
         criterion.train()
         opt = torch.optim.AdamW(get_param_dict(cfg, model), lr=cfg.lr, weight_decay=cfg.weight_decay)
         samples, targets = synthetic_batch(1, 640, 640, 5, torch.device("cpu"), seed=1)
+        targets = list(targets)
+
+        def step():
+            out = model(samples, targets)
+            loss_dict = criterion(out, targets)
+            wd = criterion.weight_dict
+            loss = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.clip_max_norm)
+            opt.step()
+        step()                                  # warm-up (allocator, oneDNN primitive caches)
         t0 = time.perf_counter()
-        out = model(samples, targets)
-        loss_dict = criterion(out, targets)
-        wd = criterion.weight_dict
-        loss = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.clip_max_norm)
-        opt.step()
+        step()
         dt = time.perf_counter() - t0
     finally:
         msda.ms_deform_attn_forward, msda.ms_deform_attn_backward, crit_mod.focal_loss_sums = saved
     return {"value": round(2.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"1 training step, 1 source + 1 target image 640x640 (BASELINE config 1 "
-                      f"shape), {dt:.1f} s on {os.cpu_count()} host cpus"}
+            "sample": f"1 training step (after 1 warm-up step), 1 source + 1 target image 640x640 "
+                      f"(BASELINE config 1 shape, DA branch included), {dt:.1f} s on "
+                      f"{os.cpu_count()} host cpus",
+            "msda_op": msda_cpu_ops(msda_gpu_us)}
+
+
+def relaunch_with_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under
+    torch.distributed.run on this node (the command line the driver uses) and pass its output
+    through."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -296,6 +298,9 @@ def main():
     ap.add_argument("--num-gt", type=int, default=10)
     ap.add_argument("--flat-grads", action="store_true", help="use the flat-bucket reducer at N=1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--padded-steps", type=int, default=4,
+                    help="after the timed region, also time this many steps of a batch that "
+                         "needs padding (general path: masks, no shape-keyed caches); 0 = skip")
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
                     help="keep the backbone in NCHW (default: NHWC / torch.channels_last, which "
                          "MIOpen's measured-fastest fp32 solvers want; same arithmetic)")
@@ -305,29 +310,37 @@ def main():
                     help="teacher: the teacher-student stage (BASELINE config 5) on one GPU; "
                          "the default is the headline burn-in step")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_with_ranks(args.gpus)
     if args.stage == "teacher":
         device = torch.device("cuda", 0)
         torch.cuda.set_device(device)
         return teacher_student_stage(args, device)
 
-    from datr_amd.dist import init_distributed
+    from datr_amd.dist import FORCE_COLLECTIVES, init_distributed
     rank, local_rank, world = init_distributed()
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1:
+        assert dist.is_initialized() and dist.get_world_size() == world and dist.get_backend() == "nccl", \
+            "the multi-GPU bench runs over RCCL (torch.distributed backend 'nccl')"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    from datr_amd.dist import FORCE_COLLECTIVES
-    trainer = Trainer(args, device, distributed=world > 1 or FORCE_COLLECTIVES)
-    samples, targets = synthetic_batch(args.batch, args.height, args.width, args.num_gt, device,
-                                       seed=1 + rank)
-    if args.channels_last:
-        samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
+    state = build_training(device=device, rank=rank, channels_last=args.channels_last,
+                           tuned_gemm=args.tuned_gemm,
+                           reducer=True if (world > 1 or FORCE_COLLECTIVES or args.flat_grads) else False)
+    # four different batches of the workload's shape, cycled (a data loader's batches differ)
+    pool = [synthetic_batch(args.batch, args.height, args.width, args.num_gt, device,
+                            seed=1 + 7 * rank + 1000 * i, channels_last=args.channels_last)
+            for i in range(4)]
     timer = MsdaTimer()
     timer.install()
 
-    for _ in range(args.warmup):
-        trainer.step(samples, targets)
+    def batches(n, offset=0):
+        return [pool[(offset + i) % len(pool)] for i in range(n)]
+
+    run_steps(state, batches(args.warmup))
 
     def fence():
         if world > 1:
@@ -337,8 +350,7 @@ def main():
     fence()
     timer.enabled = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(samples, targets)
+    run_steps(state, batches(args.steps, args.warmup))
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
@@ -348,27 +360,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    padded_ms = None
+    if args.padded_steps > 0 and world == 1:
+        # the same workload as a batch of different-sized images would arrive: images of
+        # (H-32) x W inside the H x W batch tensor, mask True on the padding
+        pb = synthetic_batch(args.batch, args.height - 32, args.width, args.num_gt, device, seed=99,
+                             channels_last=args.channels_last, pad_to=(args.height, args.width))
+        run_steps(state, [pb] * 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(state, [pb] * args.padded_steps)
+        torch.cuda.synchronize()
+        padded_ms = round((time.perf_counter() - t1) / args.padded_steps * 1e3, 2)
+
     if rank == 0:
         images = 2 * args.batch * world * args.steps
+        roof = timer.result()
         line = {
             "metric": "images/sec, DINO-4scale R50 + DATR DA branch training step, bs=2/GPU, 1333x800",
             "value": round(images / elapsed, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": "DINO-4scale R50 bs=2 1333x800 burn-in step (fwd + SetCriterion "
-                                   "+ bwd + clip + AdamW; source+target pass, D_img, prototypes)",
+            "config": {"workload": "DINO-4scale R50 bs=2 1333x800 burn-in step through "
+                                   "engine.train_one_epoch (fwd + SetCriterion + reduce_dict + bwd + "
+                                   "grad all-reduce + clip + AdamW + loss fetch/guard; source+target "
+                                   "pass, D_img, prototypes)",
                        "images_per_gpu": 2 * args.batch, "global_batch_pairs": args.batch * world,
-                       "parallelism": f"dp{world}", "num_gt_per_image": args.num_gt},
+                       "parallelism": f"dp{world}", "num_gt_per_image": args.num_gt,
+                       "grad_reducer": state.reducer is not None,
+                       "rccl_world": dist.get_world_size() if dist.is_initialized() else 1},
             "pairs_per_sec": round(images / elapsed / 2, 3),
-            "roofline": timer.result(),
+            "padded_batch_ms_per_step": padded_ms,
+            "roofline": roof,
         }
         if timer.shape is not None:
             line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
         if world == 1 and not args.no_cpu_baseline:
             if dist.is_initialized():       # one-rank RCCL mode: the CPU leg must not see a NCCL group
                 dist.destroy_process_group()
-            line["cpu_baseline"] = cpu_baseline()
+            # GPU time of the op at the CPU leg's shape (N=2): the merged N=4 launch / 2
+            gpu_us = roof["mean_us"] * 2 / timer.shape[0] if roof else None
+            line["cpu_baseline"] = cpu_baseline(gpu_us)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

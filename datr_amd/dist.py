@@ -3,23 +3,32 @@ summed over RCCL (torch.distributed backend "nccl" on ROCm) and averaged.
 
 What the reference does: wraps the model in
 `torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)`
-(/root/reference/main.py:156) -- 47.77 M fp32 gradients = 191 MB all-reduced per step in
-25 MB buckets, plus a graph walk per step to find unused parameters.
+(/root/reference/main.py:156) -- the constructor broadcasts rank 0's parameters and buffers,
+then 47.77 M fp32 gradients = 191 MB are all-reduced per step in 25 MB buckets, plus a graph
+walk per step to find unused parameters.
 
 What this module does instead:
-  * every bucket owns ONE flat fp32 buffer and each parameter's `.grad` is a view into it, so
-    there is no copy into or out of communication buffers and `zero_grad` is one memset per
-    bucket;
-  * buckets are filled in reverse parameter order (heads / decoder first, backbone layer2
-    last), and a bucket's all-reduce is launched asynchronously from the autograd hook of its
-    last-arriving gradient, so communication overlaps the rest of backward;
+  * rank 0's parameters and buffers are broadcast once at construction (coalesced per dtype), so
+    ranks seeded with `seed + rank` (main.py:138) start from the same weights, as under DDP;
+  * every bucket owns ONE flat fp32 buffer.  Autograd hands over its own gradient tensors
+    (`.grad = None` at `zero_grad`); when a bucket is launched they are moved into the flat buffer
+    with one multi-tensor copy and the buffer slices become the parameters' `.grad`, so the
+    optimizer and the clip read the reduced values without a copy-out;
+  * collectives are issued in a FIXED ORDER -- bucket i only after buckets 0..i-1 -- on every
+    rank, whatever order the gradients arrive in locally (ranks may differ: a rank without boxes
+    or pseudo labels produces fewer gradients).  A bucket whose predecessors are launched is
+    launched from the autograd hook of its last-arriving gradient, so communication overlaps the
+    rest of backward; whatever is left is launched from `finish()`;
+  * the fixed order is the order in which rank 0's gradients became ready in the FIRST step
+    (broadcast, then the buckets are rebuilt once -- what DDP's bucket rebuild does), so
+    in steady state a bucket completes when its predecessors already have and nothing waits for
+    `finish()`; the last-produced gradients (backbone layer2) get a small bucket of their own so
+    that the reduction left over after backward is short;
   * xGMI is point-to-point (7 links x ~153 GB/s), so a ring all-reduce is per-link bound:
     fewer, larger buckets amortise launch latency better than DDP's 25 MB default -- the
-    default here is 64 MB (3 buckets for 191 MB), with a small FIRST bucket so that the
-    reduction of the last gradients produced (backbone layer2) is short;
+    default here is 64 MB (3-4 buckets for 191 MB);
   * parameters that received no gradient in a step (the reference needs
-    find_unused_parameters=True for those) simply keep their zero-filled view, and their
-    bucket is launched from `finish()` -- no graph walk, no hang.
+    find_unused_parameters=True for those) contribute their zero-filled slice -- no graph walk.
 Shared modules (the six aliased detection heads) appear once: parameters are de-duplicated by
 identity, as `nn.Module.parameters()` already does.
 """
@@ -39,6 +48,30 @@ EXTRA_STREAMS = []
 # world size 1 -- lets a 1-GPU box exercise the real RCCL code path (async all-reduce from autograd
 # hooks, stream ordering); values are unchanged (sum over one rank, divided by 1)
 FORCE_COLLECTIVES = __import__("os").environ.get("DATR_DIST_FORCE_COLLECTIVES", "0") == "1"
+
+
+def broadcast_module_state(module: nn.Module, src: int = 0, group=None):
+    """Rank `src`'s parameters and buffers to every rank, one broadcast per dtype (what the DDP
+    constructor does, /root/reference/main.py:156).  Aliased tensors are sent once."""
+    if not dist.is_initialized():
+        return
+    seen, by_dtype = set(), {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        if id(t) in seen or t.numel() == 0:
+            continue
+        seen.add(id(t))
+        by_dtype.setdefault((t.dtype, t.device), []).append(t.data)
+    for (dtype, device), tensors in by_dtype.items():
+        wire = dtype if dtype != torch.bool else torch.uint8
+        flat = torch.cat([t.reshape(-1).to(wire) for t in tensors])
+        dist.broadcast(flat, src=src, group=group)
+        offset = 0
+        for t in tensors:
+            n = t.numel()
+            # a dense tensor's storage order is its own (channels_last weights included):
+            # reshape(-1) above walked logical order, so write back through logical order too
+            t.copy_(flat[offset:offset + n].view(t.shape).to(dtype))
+            offset += n
 
 
 class _Bucket:
@@ -68,66 +101,109 @@ class _Bucket:
         self.work = None
         self.event = None
         self.launched = False
+        # stream the bucket's last gradient was produced on (hooks of later buckets may launch
+        # this one from a different stream)
+        self.ready_stream = None
 
 
 class GradAllReducer:
     """Usage per step:  reducer.zero_grad(); loss.backward(); reducer.finish(); clip; step."""
 
     def __init__(self, model: nn.Module, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0,
-                 process_group=None, side_params=None):
+                 process_group=None, side_params=None, broadcast: bool = True,
+                 rebuild: bool = True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # RCCL averages inside the collective (no division pass over the buckets afterwards); gloo
         # has no AVG: sum, then divide in finish()
         nccl = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
-        params = [p for p in model.parameters() if p.requires_grad]
-        assert params, "no trainable parameters"
-        device, dtype = params[0].device, params[0].dtype
+        if broadcast and dist.is_initialized() and self.world > 1:
+            broadcast_module_state(model, 0, process_group)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        self._index = {p: i for i, p in enumerate(self.params)}
+        self.device, self.dtype = self.params[0].device, self.params[0].dtype
         if side_params is None:
             side_params = getattr(model, "side_stream_parameters", lambda: [])()
-        side_ids = {id(p) for p in side_params}
-        side = [p for p in params if id(p) in side_ids]
-        params = [p for p in params if id(p) not in side_ids]
-        # gradients become ready roughly in reverse registration order
-        order = list(reversed(params))
+        self._side_ids = {id(p) for p in side_params}
+        self._cap = int(bucket_mb * (1 << 20) / 4)
+        self._tail_cap = int(first_bucket_mb * (1 << 20) / 4)
+        # first step: gradients become ready roughly in reverse registration order
         self.buckets: List[_Bucket] = []
-        cap = int(bucket_mb * (1 << 20) / 4)
-        first_cap = int(first_bucket_mb * (1 << 20) / 4)
-        # the LAST gradients to arrive (front of `params`) get their own small bucket
-        tail: List[nn.Parameter] = []
+        self._build(list(reversed(range(len(self.params)))))
+        self._arrival: Optional[List[int]] = [] if rebuild else None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    # -- bucket layout --------------------------------------------------------------------------
+    def _build(self, order: List[int]):
+        """Buckets over the parameters in `order` (expected readiness order).  Main-stream
+        parameters: the last ones (<= tail capacity) form a small final bucket, the rest is cut
+        into `cap`-sized buckets from the front.  Side-stream parameters share one bucket.  The
+        launch order of the buckets is the position of their LAST parameter in `order`."""
+        pos = {i: k for k, i in enumerate(order)}
+        main = [i for i in order if id(self.params[i]) not in self._side_ids]
+        side = [i for i in order if id(self.params[i]) in self._side_ids]
+        groups: List[tuple] = []
+        tail: List[int] = []
         size = 0
-        while order and size + order[-1].numel() <= first_cap:
-            p = order.pop()
-            tail.append(p)
-            size += p.numel()
-        cur: List[nn.Parameter] = []
-        size = 0
-        for p in order:
-            if cur and size + p.numel() > cap:
-                self.buckets.append(_Bucket(cur, device, dtype))
+        while main and size + self.params[main[-1]].numel() <= self._tail_cap:
+            i = main.pop()
+            tail.append(i)
+            size += self.params[i].numel()
+        cur, size = [], 0
+        for i in main:
+            n = self.params[i].numel()
+            if cur and size + n > self._cap:
+                groups.append((cur, False))
                 cur, size = [], 0
-            cur.append(p)
-            size += p.numel()
+            cur.append(i)
+            size += n
         if cur:
-            self.buckets.append(_Bucket(cur, device, dtype))
+            groups.append((cur, False))
         if tail:
-            self.buckets.append(_Bucket(list(reversed(tail)), device, dtype))
-        if side:                         # parameters whose gradients are produced on a side stream
-            self.buckets.append(_Bucket(side, device, dtype, side=True))
-        self._bucket_of = {}
-        self._hooks = []
-        for b in self.buckets:
-            for p in b.params:
-                self._bucket_of[p] = b
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            groups.append((list(reversed(tail)), False))
+        if side:
+            groups.append((side, True))
+        groups.sort(key=lambda g: max(pos[i] for i in g[0]))
+        self.buckets = [_Bucket([self.params[i] for i in idx], self.device, self.dtype, side=s)
+                        for idx, s in groups]
+        self._bucket_of = {p: b for b in self.buckets for p in b.params}
+        self._next = 0
+
+    def _rebuild_from_first_step(self):
+        """After the first backward: adopt rank 0's gradient arrival order (parameters that got
+        no gradient go last, in reverse registration order) and re-cut the buckets.  Every rank
+        calls this at the same point (first `finish()`), so the broadcast is matched."""
+        seen = set(self._arrival)
+        order = self._arrival + [i for i in reversed(range(len(self.params))) if i not in seen]
+        self._arrival = None
+        if dist.is_initialized() and self.world > 1:
+            t = torch.tensor(order, dtype=torch.int64, device=self.device)
+            dist.broadcast(t, src=0, group=self.group)
+            order = t.tolist()
+        kept = [None if p.grad is None else p.grad.clone() for p in self.params]
+        self._build(order)              # new flat buffers; resets every .grad
+        for p, g in zip(self.params, kept):
+            p.grad = g
 
     # -- hooks ----------------------------------------------------------------------------------
     def _on_grad(self, p: nn.Parameter):
+        if self._arrival is not None:
+            self._arrival.append(self._index[p])
         b = self._bucket_of[p]
         b.pending -= 1
-        if b.pending == 0 and not b.launched:
-            self._launch(b)
+        if b.pending == 0:
+            if b.flat.is_cuda:
+                b.ready_stream = torch.cuda.current_stream(b.flat.device)
+            self._launch_ready()
+
+    def _launch_ready(self):
+        """Launch, in index order, every bucket whose gradients are all there -- and stop at the
+        first one that still waits: the sequence of collectives is the same on every rank."""
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _gather(self, b: _Bucket, stream=None):
         """Move the gradients autograd produced into the flat buffer with ONE multi-tensor copy and
@@ -151,23 +227,29 @@ class GradAllReducer:
             p.grad = v
 
     def _launch(self, b: _Bucket):
-        """Gather the bucket and start its all-reduce from the CURRENT stream (the one autograd
-        produced the bucket's last gradient on).  No helper stream: every cross-stream wait costs
-        an event record on the compute stream, and a dozen of them per step measured ~1.9 ms.
-        Only a bucket of side-stream parameters (the detector's image-level discriminator runs on
-        its own stream, detector.py) may see gradients from another stream; that bucket first
-        waits for the streams in EXTRA_STREAMS / the default stream."""
+        """Gather the bucket and start its all-reduce from the CURRENT stream.  Usually that is
+        the stream autograd produced the bucket's last gradient on: then there is no cross-stream
+        wait at all (every such wait costs an event record on the compute stream, and a dozen of
+        them per step measured ~1.9 ms).  Waits are inserted only when gradients may have been
+        produced elsewhere: a bucket of side-stream parameters (the detector's image-level
+        discriminator runs on its own stream, detector.py) waits for EXTRA_STREAMS / the default
+        stream, and a bucket that became ready on another stream than the one it is launched
+        from (ordered launching can defer it to a later hook) waits for that stream."""
         b.launched = True
         collective = self.world > 1 or FORCE_COLLECTIVES
         foreign = None
         if b.flat.is_cuda:
             dev = b.flat.device
             cur = torch.cuda.current_stream(dev)
-            if b.side:
-                for s in [torch.cuda.default_stream(dev)] + list(EXTRA_STREAMS):
-                    if s != cur and s.device == dev:
-                        cur.wait_stream(s)
-                foreign = cur
+            wait = []
+            if b.side or b.pending > 0:
+                wait = [torch.cuda.default_stream(dev)] + list(EXTRA_STREAMS)
+            elif b.ready_stream is not None and b.ready_stream != cur:
+                wait = [b.ready_stream]
+            for s in wait:
+                if s != cur and s.device == dev:
+                    cur.wait_stream(s)
+                    foreign = cur
         self._gather(b, foreign)
         if collective:
             b.work = dist.all_reduce(b.flat, op=self._op, group=self.group, async_op=True)
@@ -184,16 +266,19 @@ class GradAllReducer:
             b.flat.zero_()
             b.pending = len(b.params)
             b.launched = False
+            b.ready_stream = None
             for p in b.params:          # autograd then hands over its gradient tensor as it is
                 p.grad = None
+        self._next = 0
 
     def finish(self):
-        """Call after backward: launches buckets that still wait for gradients that will never
-        come (unused parameters this step), waits for every gather / all-reduce and averages.
-        Afterwards every bucketed parameter's .grad is its slice of the flat buffer."""
-        for b in self.buckets:
-            if not b.launched:
-                self._launch(b)
+        """Call after backward: launches, in order, the buckets that are still waiting (their
+        missing gradients will never come: unused parameters this step), waits for every gather /
+        all-reduce and averages.  Afterwards every bucketed parameter's .grad is its slice of
+        the flat buffer."""
+        for b in self.buckets[self._next:]:
+            self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
@@ -203,6 +288,10 @@ class GradAllReducer:
                 b.event = None
             if self.world > 1 and self._op == dist.ReduceOp.SUM:
                 b.flat.div_(self.world)
+        if self._arrival is not None:
+            self._rebuild_from_first_step()
+            for b in self.buckets:      # re-home this step's (already reduced) gradients
+                self._gather(b)
 
     def remove(self):
         for h in self._hooks:
@@ -212,6 +301,23 @@ class GradAllReducer:
     @property
     def total_bytes(self) -> int:
         return sum(b.numel for b in self.buckets) * 4
+
+
+def reducer_for(model: nn.Module, args=None) -> Optional[GradAllReducer]:
+    """The reducer the epoch functions (datr_amd.engine) synchronise gradients with: `args.reducer`
+    if the caller made one, otherwise one per model, created on first use whenever a process
+    group with more than one rank is up (or DATR_DIST_FORCE_COLLECTIVES=1) and the model is not
+    already wrapped in DistributedDataParallel.  None = single process, plain `.grad`s."""
+    r = getattr(args, "reducer", None) if args is not None else None
+    if r is not None:
+        return r
+    if isinstance(model, nn.parallel.DistributedDataParallel):
+        return None
+    r = model.__dict__.get("_grad_reducer")
+    if r is None and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
+        r = GradAllReducer(model)
+        model.__dict__["_grad_reducer"] = r
+    return r
 
 
 def init_distributed(backend: Optional[str] = None):
@@ -232,6 +338,8 @@ def init_distributed(backend: Optional[str] = None):
             torch.cuda.set_device(local_rank)
         elif torch.cuda.is_available():
             local_rank = local_rank % torch.cuda.device_count()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
         dist.barrier()
     return rank, local_rank, world

@@ -3,8 +3,8 @@
 Mirror of /root/reference/models/dino/EMA.py: `ModelEMA` (:21-54, decay ramp
 d(k) = decay * (1 - exp(-k / 2000)), updated once per EPOCH by /root/reference/main.py:382) and
 `CosineEMA` (:92-135).  The per-tensor python loop over the 640 state_dict entries
-(`v *= d; v += (1 - d) * msd[k]`, EMA.py:46-50) becomes two multi-tensor (foreach) launches over
-the floating-point entries -- same arithmetic per element.
+(`v *= d; v += (1 - d) * msd[k]`, EMA.py:46-50) becomes two multi-tensor (foreach) launches per
+alias multiplicity over the floating-point entries (see `_ema_update_` for the aliased heads).
 """
 from __future__ import annotations
 
@@ -33,15 +33,29 @@ def copy_attr(a, b, include=(), exclude=()):
 
 @torch.no_grad()
 def _ema_update_(ema_model: nn.Module, model: nn.Module, d: float) -> None:
+    """The reference walks the state_dict KEYS (EMA.py:46-50), so a tensor that appears under k
+    keys -- the detection heads shared by the six decoder layers: `bbox_embed.0..5.*`,
+    `class_embed.0..5.*` and their `transformer.decoder.*` aliases, 12 keys per tensor -- is
+    updated k times per call: v <- d^k v + (1 - d^k) m.  Reproduced here as ONE update with the
+    effective decay d^k per alias group (equal up to rounding), not "fixed" to a single update:
+    the teacher's heads are meant to track the student the way the reference's do."""
     msd = _unwrap(model).state_dict()
-    dst, src, seen = [], [], set()
+    first, count = {}, {}
     for k, v in ema_model.state_dict().items():
-        if v.dtype.is_floating_point and v.data_ptr() not in seen:    # aliased heads: once
-            seen.add(v.data_ptr())
-            dst.append(v)
-            src.append(msd[k].detach())
-    torch._foreach_mul_(dst, d)
-    torch._foreach_add_(dst, src, alpha=1.0 - d)
+        if v.dtype.is_floating_point:
+            ptr = v.data_ptr()
+            if ptr not in first:
+                first[ptr] = (v, msd[k].detach())
+            count[ptr] = count.get(ptr, 0) + 1
+    by_k = {}
+    for ptr, (v, m) in first.items():
+        dst, src = by_k.setdefault(count[ptr], ([], []))
+        dst.append(v)
+        src.append(m)
+    for k, (dst, src) in by_k.items():
+        dk = d ** k
+        torch._foreach_mul_(dst, dk)
+        torch._foreach_add_(dst, src, alpha=1.0 - dk)
 
 
 class ModelEMA:

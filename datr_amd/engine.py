@@ -15,30 +15,70 @@ from typing import Iterable
 import torch
 
 from .criterion import weighted_total
+from .dist import reducer_for
 from .nested import reduce_dict
 
 
+class _LossFetch:
+    """The reduced loss dict on its way to the host: ONE stacked device tensor copied into pinned
+    memory without blocking (the reference calls .item() / float() per entry: ~170 synchronising
+    copies per step).  `result()` waits for that copy only -- it is called after backward, clip
+    and optimizer step have been enqueued, so the host never drains the GPU's queue mid-step.
+    The non-finite guard it feeds ends the process (engine.py:81-84), so whether the dying
+    process had already enqueued its update is unobservable; the values are the reference's."""
+
+    def __init__(self, loss_dict_reduced, weight_dict):
+        self.keys = list(loss_dict_reduced)
+        self.weight_dict = weight_dict
+        self.event = None
+        vals = [loss_dict_reduced[k] for k in self.keys]
+        if self.keys and all(torch.is_tensor(v) for v in vals):
+            dev = torch.stack([v.detach().float().reshape(()) for v in vals])
+            if dev.is_cuda:
+                self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+                self.host.copy_(dev, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record()
+            else:
+                self.host = dev
+        else:
+            self.host = [float(v) for v in vals]
+
+    def result(self):
+        """({key: loss * weight} for weighted keys, {key: loss}) as python floats."""
+        if self.event is not None:
+            self.event.synchronize()
+        host = self.host.tolist() if torch.is_tensor(self.host) else self.host
+        unscaled = dict(zip(self.keys, host))
+        scaled = {k: v * float(self.weight_dict[k]) for k, v in unscaled.items()
+                  if k in self.weight_dict}
+        return scaled, unscaled
+
+
 def _losses_to_host(loss_dict_reduced, weight_dict):
-    """({key: loss * weight} for weighted keys, {key: loss}) as python floats with ONE
-    device->host transfer (the reference calls .item() / float() per entry: ~170 synchronising
-    copies per step)."""
-    keys = list(loss_dict_reduced)
-    if not keys:
-        return {}, {}
-    vals = [loss_dict_reduced[k] for k in keys]
-    if all(torch.is_tensor(v) for v in vals):
-        host = torch.stack([v.detach().float().reshape(()) for v in vals]).tolist()
+    return _LossFetch(loss_dict_reduced, weight_dict).result()
+
+
+def _check_finite(loss_value, loss_dict_reduced):
+    if not math.isfinite(loss_value):
+        print(f"Loss is {loss_value}, stopping training")
+        print(loss_dict_reduced)
+        sys.exit(1)
+
+
+def _backward_and_step(model, optimizer, losses, max_norm, scaler, amp, reducer=None):
+    """zero_grad / backward / gradient all-reduce / clip / step (engine.py:86-104).  With a
+    reducer (datr_amd.dist.GradAllReducer: the counterpart of the reference's DDP wrapper,
+    main.py:156) the gradients live in its flat buckets and are averaged over the ranks while
+    backward is still running."""
+    if reducer is not None:
+        reducer.zero_grad()
     else:
-        host = [float(v) for v in vals]
-    unscaled = dict(zip(keys, host))
-    scaled = {k: v * float(weight_dict[k]) for k, v in unscaled.items() if k in weight_dict}
-    return scaled, unscaled
-
-
-def _backward_and_step(model, optimizer, losses, max_norm, scaler, amp):
-    optimizer.zero_grad()
+        optimizer.zero_grad()
     if amp:
         scaler.scale(losses).backward()
+        if reducer is not None:
+            reducer.finish()
         if max_norm > 0:
             scaler.unscale_(optimizer)
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
@@ -46,6 +86,8 @@ def _backward_and_step(model, optimizer, losses, max_norm, scaler, amp):
         scaler.update()
     else:
         losses.backward()
+        if reducer is not None:
+            reducer.finish()
         if max_norm > 0:
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
         optimizer.step()
@@ -58,6 +100,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     amp = bool(getattr(args, "amp", False))
     scaler = torch.amp.GradScaler("cuda", enabled=amp)
     need_tgt_for_training = bool(getattr(args, "use_dn", False))
+    reducer = reducer_for(model, args)
     model.train()
     criterion.train()
     sums, counts = defaultdict(float), defaultdict(int)
@@ -75,26 +118,11 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             losses = weighted_total(loss_dict, weight_dict)
 
         loss_dict_reduced = {k: v.detach() for k, v in reduce_dict(loss_dict).items()}
-        scaled, unscaled = _losses_to_host(loss_dict_reduced, weight_dict)
+        fetch = _LossFetch(loss_dict_reduced, weight_dict)
+        _backward_and_step(model, optimizer, losses, max_norm, scaler, amp, reducer)
+        scaled, unscaled = fetch.result()
         loss_value = sum(scaled.values())
-        if not math.isfinite(loss_value):
-            print(f"Loss is {loss_value}, stopping training")
-            print(loss_dict_reduced)
-            sys.exit(1)
-
-        optimizer.zero_grad()
-        if amp:
-            scaler.scale(losses).backward()
-            if max_norm > 0:
-                scaler.unscale_(optimizer)
-                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-            scaler.step(optimizer)
-            scaler.update()
-        else:
-            losses.backward()
-            if max_norm > 0:
-                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-            optimizer.step()
+        _check_finite(loss_value, loss_dict_reduced)
         if getattr(args, "onecyclelr", False):
             lr_scheduler.step()
         if getattr(args, "use_ema", False) and epoch >= getattr(args, "ema_epoch", 0):
@@ -139,6 +167,7 @@ def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loa
     need_tgt_for_training = bool(getattr(args, "use_dn", False))
     model.train()
     criterion.train()
+    reducer = reducer_for(model, args)
     post = PostProcess()                      # default-constructed: num_select = 100 (engine.py:159)
     loader = data_loader_strong_aug if data_loader_strong_aug is not None else data_loader
     sums, counts = defaultdict(float), defaultdict(int)
@@ -184,13 +213,11 @@ def train_one_epoch_with_self_training(model, teacher_model, criterion, data_loa
             losses = losses_source + losses_target * weight_dict["loss_self_training"]
 
         loss_dict_reduced = reduce_dict(loss_dict_source)
-        scaled, unscaled = _losses_to_host(loss_dict_reduced, weight_dict)
+        fetch = _LossFetch(loss_dict_reduced, weight_dict)
+        _backward_and_step(model, optimizer, losses, max_norm, scaler, amp, reducer)
+        scaled, unscaled = fetch.result()
         loss_value = sum(scaled.values())
-        if not math.isfinite(loss_value):
-            print(f"Loss is {loss_value}, stopping training")
-            print(loss_dict_reduced)
-            sys.exit(1)
-        _backward_and_step(model, optimizer, losses, max_norm, scaler, amp)
+        _check_finite(loss_value, loss_dict_reduced)
         if getattr(args, "onecyclelr", False):
             lr_scheduler.step()
         if getattr(args, "use_ema", False) and epoch >= getattr(args, "ema_epoch", 0):

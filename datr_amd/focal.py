@@ -59,6 +59,12 @@ def sigmoid_focal_loss_sums(logits: torch.Tensor, target: torch.Tensor, alpha: f
     positive) -> [G] sums of the element-wise focal loss."""
     if not logits.is_cuda:
         raise RuntimeError("sigmoid_focal_loss_sums: Not implemented on the CPU")
+    if logits.dtype in (torch.float16, torch.bfloat16):
+        # under autocast (engine's `args.amp`) the class logits arrive in half precision; the
+        # reference's focal loss promotes them to fp32 as well (utils.py:79-104 runs sigmoid /
+        # BCE-with-logits, both on autocast's fp32 list).  `.float()` is differentiable: the
+        # gradient comes back in the logits' dtype.
+        logits = logits.float()
     if logits.dtype != torch.float32:
         raise RuntimeError(f"sigmoid_focal_loss_sums: float32 only, got {logits.dtype}")
     return _FocalSums.apply(logits.contiguous(), target.to(torch.int64).contiguous(), alpha, gamma)
@@ -101,6 +107,9 @@ def box_loss_sums(src: torch.Tensor, tgt: torch.Tensor, group: torch.Tensor, G: 
     """src, tgt [P, 4] cxcywh fp32 on the device, group [P] int64 in [0, G) -> [4, G] sums of the
     L1 distance, of 1 - GIoU(xyxy(src), xyxy(tgt)) (box_ops.py:40-63, 1e-6 terms included), and
     of the xy / wh halves of the L1, per prediction set.  Rows 2, 3 are for logging: no gradient."""
+    if src.dtype in (torch.float16, torch.bfloat16):      # autocast: box losses are fp32 work
+        src = src.float()
+    tgt = tgt.to(src.dtype)
     assert src.is_cuda and src.dtype == torch.float32 and src.shape == tgt.shape and src.shape[-1] == 4
     assert 0 < src.shape[0] <= MAX_BOX_LOSS_PAIRS and group.dtype == torch.int64
     return _BoxLossSums.apply(src, tgt.detach(), group, int(G))

@@ -70,16 +70,20 @@ TILED_FORWARD = __import__("os").environ.get("DATR_MSDA_TILED_FWD", "0") == "1"
 
 
 def _host_meta(shapes: torch.Tensor, lsi: torch.Tensor):
-    """Host copies (numpy int64) of the two small geometry tensors, cached by storage address
-    and version so that a training loop pays the device->host copy once per geometry, not per
-    call (datr_amd.transformer caches the device tensors per feature-map geometry)."""
+    """Host copies (numpy int64) of the two small geometry tensors, cached so that a training
+    loop pays the device->host copy once per geometry, not per call.  The key is the storage
+    address + version of both tensors; the entry HOLDS the two tensors, so their storage cannot
+    be freed and handed to a different geometry while the key is in the cache (an address is an
+    identity only for as long as its owner lives -- whoever else caches the device tensors,
+    e.g. datr_amd.transformer._level_meta, may drop them at any time)."""
     key = (shapes.data_ptr(), shapes._version, lsi.data_ptr(), lsi._version, shapes.shape[0])
     hit = _HOST_META.get(key)
     if hit is None:
         if len(_HOST_META) > 256:
             _HOST_META.clear()
-        hit = _HOST_META[key] = (shapes.cpu().numpy().copy(), lsi.cpu().numpy().copy())
-    return hit
+        hit = _HOST_META[key] = (shapes.cpu().numpy().copy(), lsi.cpu().numpy().copy(),
+                                 (shapes, lsi))
+    return hit[0], hit[1]
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
@@ -234,18 +238,19 @@ _INV_WH = {}
 
 def _inverse_wh(spatial_shapes: torch.Tensor, n_heads: int, n_points: int) -> torch.Tensor:
     """[n_heads * L * n_points * 2] vector of 1/W_l, 1/H_l in the layout of the sampling_offsets
-    output (head, level, point, xy); cached per geometry tensor (transformer._level_meta keeps
-    one tensor per pyramid geometry alive, so the pointer identifies it)."""
-    key = (spatial_shapes.data_ptr(), str(spatial_shapes.device), n_heads, n_points,
-           tuple(spatial_shapes.shape))
-    inv = _INV_WH.get(key)
-    if inv is None:
+    output (head, level, point, xy); cached per geometry tensor.  As in `_host_meta`, the entry
+    keeps the geometry tensor alive, so its address cannot be recycled for another pyramid while
+    it serves as the key."""
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, str(spatial_shapes.device), n_heads,
+           n_points, tuple(spatial_shapes.shape))
+    hit = _INV_WH.get(key)
+    if hit is None:
         if len(_INV_WH) > 64:
             _INV_WH.clear()
         wh = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1).to(torch.float32)
         inv = (1.0 / wh)[None, :, None, :].expand(n_heads, -1, n_points, -1).reshape(-1).contiguous()
-        _INV_WH[key] = inv
-    return inv
+        hit = _INV_WH[key] = (inv, spatial_shapes)
+    return hit[0]
 
 
 class MSDeformAttn(nn.Module):

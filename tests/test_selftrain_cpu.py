@@ -91,3 +91,37 @@ def test_no_pseudo_labels_keeps_the_step_alive(monkeypatch):
                                                torch.device("cpu"), 0, args.clip_max_norm, args=args)
     assert stats["_last"]["num_pseudo_images"] == 0 and stats["_last"]["target_loss_dict"] == {}
     assert np.isfinite(stats["loss"])
+
+
+def test_ema_update_of_aliased_heads_follows_the_per_key_loop():
+    """the reference updates once per state_dict KEY (EMA.py:46-50); the detector's
+    shared heads sit under 12 keys each, so their effective decay is d^12.  Checked on the real
+    detector against the per-key loop written out."""
+    from datr_amd.ema import ModelEMA
+    args, model, _, _ = build_model()
+    teacher = ModelEMA(model, decay=0.9996, updates=5000)
+    expect = {k: v.clone() for k, v in teacher.ema.state_dict().items()}
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    d = teacher.decay(5001)
+    msd = model.state_dict()
+    # the reference's loop on a private copy that keeps the aliasing
+    import copy
+    shadow = copy.deepcopy(teacher.ema)
+    with torch.no_grad():
+        for k, v in shadow.state_dict().items():
+            if v.dtype.is_floating_point:
+                v *= d
+                v += (1.0 - d) * msd[k].detach()
+    teacher.update(model)
+    aliases = {}
+    for k, v in teacher.ema.state_dict().items():
+        aliases.setdefault(v.data_ptr(), []).append(k)
+    assert max(len(v) for v in aliases.values()) == 12
+    for (k, mine), (_, ref) in zip(teacher.ema.state_dict().items(), shadow.state_dict().items()):
+        torch.testing.assert_close(mine, ref, rtol=1e-6, atol=1e-7, msg=k)
+    # and the aliased heads did move (1 - d^12) / (1 - d) ~ 7.8x further than a single update would have
+    k = "class_embed.0.weight"
+    single = expect[k] * d + (1 - d) * msd[k]
+    assert float((teacher.ema.state_dict()[k] - expect[k]).norm()) > 5 * float((single - expect[k]).norm())

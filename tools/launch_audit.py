@@ -2,7 +2,7 @@
 import os, sys, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
+from datr_amd import training as bench
 from torch.profiler import profile, ProfilerActivity
 
 
@@ -13,7 +13,7 @@ class A:
 
 
 dev = torch.device("cuda:0")
-tr = bench.Trainer(A, dev, distributed=False)
+tr = bench.Stepper(dev)
 samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
 samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
 for _ in range(3):

@@ -8,7 +8,7 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+from datr_amd import training as bench  # noqa: E402
 
 
 class A:
@@ -19,7 +19,7 @@ class A:
 
 LIMIT_US = 20.0
 dev = torch.device("cuda:0")
-tr = bench.Trainer(A, dev, distributed=False)
+tr = bench.Stepper(dev)
 samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
 samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
 # no python stacks in this build's profiler: label regions by wrapping the callables

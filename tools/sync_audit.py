@@ -9,7 +9,7 @@ import warnings
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+from datr_amd import training as bench  # noqa: E402
 
 
 def main():
@@ -28,7 +28,7 @@ def main():
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", rank=0, world_size=1)
     args = argparse.Namespace(tuned_gemm=True, channels_last=True, flat_grads=False)
-    tr = bench.Trainer(args, dev, cli.dist)
+    tr = bench.Stepper(dev, reducer=bool(cli.dist))
     hh, ww = (256, 320) if cli.small else (800, 1333)
     samples, targets = bench.synthetic_batch(2, hh, ww, 10, dev, seed=1)
     for _ in range(3):

@@ -2,7 +2,7 @@
 import os, sys, argparse
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
+from datr_amd import training as bench
 from torch.profiler import profile, ProfilerActivity
 
 ap = argparse.ArgumentParser(); ap.add_argument("--rows", type=int, default=60); a = ap.parse_args()
@@ -10,7 +10,7 @@ class A:
     flat_grads = False
     tuned_gemm = True
 dev = torch.device("cuda:0")
-tr = bench.Trainer(A, dev, distributed=False)
+tr = bench.Stepper(dev)
 samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
 for _ in range(3): tr.step(samples, targets)
 torch.cuda.synchronize()
