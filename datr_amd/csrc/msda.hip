@@ -636,13 +636,17 @@ int datr_msda_forward_tiled_f32(const float *value, const int64_t *shapes,
                                 const int64_t *level_start_host, const float *loc,
                                 const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
                                 int64_t L, int64_t Lq, int64_t P, float *out, void *stream) {
-    DatrTiledMeta meta;
-    if (P != 4 || L > 4 ||
-        !build_tiled_meta(meta, shapes_host, level_start_host, N, S, M, D, L, Lq, P, false))
-        return datr_msda_forward_f32(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
-                                     out, stream);
-    if (!value || !loc || !attn || !out) return DATR_EINVAL;
-    return datr_internal_msda_fwd_win_d32(value, loc, attn, &meta, N, S, M, P, out, stream);
+    if (!dims_ok(N, S, M, D, L, Lq, P)) return DATR_EINVAL;
+    if (N == 0 || Lq == 0) return DATR_OK;
+    if (!value || !shapes || !level_start || !loc || !attn || !out) return DATR_EINVAL;
+    if (shapes_host && level_start_host) {
+        // encoder calls: pyramid-region kernel, levels 1..3 gathered out of LDS (msda_fwd_pyr.hip)
+        const int rc = datr_internal_msda_fwd_pyr_d32(value, loc, attn, shapes_host, level_start_host,
+                                                      N, S, M, D, L, Lq, P, out, stream);
+        if (rc != DATR_EUNSUPPORTED) return rc;
+    }
+    return datr_msda_forward_f32(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out,
+                                 stream);
 }
 
 int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
