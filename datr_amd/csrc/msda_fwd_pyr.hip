@@ -90,6 +90,11 @@ __device__ __forceinline__ void fma4(f4 &acc, float w, const f4 v) {
     acc.w = fmaf(w, v.w, acc.w);
 }
 
+// Program-order fence for the staged gathers: the accumulators must hold everything accumulated
+// so far, and no memory access moves across.  (`sched_barrier` alone does not do it: the FMAs are
+// pure, so instruction selection is free to sink them below the fence.)
+#define PIN(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
+
 // Corner rows of point P of the level whose geometry lane SRC of the quad holds, the lane's two
 // 16-B pieces of each.  GLOBAL: the "addresses" are byte offsets for zero-filling buffer loads;
 // otherwise LDS byte addresses.
@@ -132,15 +137,15 @@ __device__ __forceinline__ void lds_level(f4 &acc0, f4 &acc1, const int (&addr)[
     f4 va[4], vb[4], wa[4], wb[4];
     fetch_point<SRC, false>(va, vb, addr[0], chan, lds, rsrc);
     fetch_point<SRC, false>(wa, wb, addr[1], chan, lds, rsrc);
-    __builtin_amdgcn_sched_barrier(0);
+    PIN(acc0, acc1);
     accumulate_point<SRC>(acc0, acc1, va, vb, wgt[0]);
     fetch_point<SRC, false>(va, vb, addr[2], chan, lds, rsrc);
-    __builtin_amdgcn_sched_barrier(0);
+    PIN(acc0, acc1);
     accumulate_point<SRC>(acc0, acc1, wa, wb, wgt[1]);
     fetch_point<SRC, false>(wa, wb, addr[3], chan, lds, rsrc);
-    __builtin_amdgcn_sched_barrier(0);
+    PIN(acc0, acc1);
     accumulate_point<SRC>(acc0, acc1, va, vb, wgt[2]);
-    __builtin_amdgcn_sched_barrier(0);
+    PIN(acc0, acc1);
     accumulate_point<SRC>(acc0, acc1, wa, wb, wgt[3]);
 }
 
@@ -317,18 +322,18 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_pyr_d32(
             f4 ga[2][4], gb[2][4];
             fetch_point<0, true>(ga[0], gb[0], addr[0], chan, lds, rsrc);
             fetch_point<0, true>(ga[1], gb[1], addr[1], chan, lds, rsrc);
-            __builtin_amdgcn_sched_barrier(0);
+            PIN(acc0, acc1);
             lds_level<1>(acc0, acc1, addr, wgt, chan, lds, rsrc);
-            __builtin_amdgcn_sched_barrier(0);
+            PIN(acc0, acc1);
             accumulate_point<0>(acc0, acc1, ga[0], gb[0], wgt[0]);
             accumulate_point<0>(acc0, acc1, ga[1], gb[1], wgt[1]);
             fetch_point<0, true>(ga[0], gb[0], addr[2], chan, lds, rsrc);
             fetch_point<0, true>(ga[1], gb[1], addr[3], chan, lds, rsrc);
-            __builtin_amdgcn_sched_barrier(0);
+            PIN(acc0, acc1);
             lds_level<2>(acc0, acc1, addr, wgt, chan, lds, rsrc);
-            __builtin_amdgcn_sched_barrier(0);
+            PIN(acc0, acc1);
             lds_level<3>(acc0, acc1, addr, wgt, chan, lds, rsrc);
-            __builtin_amdgcn_sched_barrier(0);
+            PIN(acc0, acc1);
             accumulate_point<0>(acc0, acc1, ga[0], gb[0], wgt[2]);
             accumulate_point<0>(acc0, acc1, ga[1], gb[1], wgt[3]);
         }

@@ -60,13 +60,12 @@ def _as_int64(t: torch.Tensor) -> torch.Tensor:
 
 
 _HOST_META = {}
-# The query-tiled forward (csrc/msda_fwd_tiled.hip) is correct and tested but, as measured in
-# round 1, SLOWER than the row kernel on the encoder call (158 us vs 105 us: four
-# stage -> barrier -> gather -> barrier rounds at 16 waves per CU are latency-bound), so the row
-# kernel stays the default.  DATR_MSDA_TILED_FWD=1 switches it on for A/B measurements.
+# Encoder calls (Lq == S, D == 32, L == P == 4) take the pyramid-region forward of
+# csrc/msda_fwd_pyr.hip (levels 1..3 gathered out of LDS, level 0 through the vector-memory
+# path); everything else the row kernel.  DATR_MSDA_PYR_FWD=0 forces the row kernel (A/B runs).
 TILED_BACKWARD_MIN_LQ = int(__import__("os").environ.get("DATR_MSDA_TILED_BWD_MIN_LQ", "64"))
 MERGE_QUERY_PROJECTIONS = __import__("os").environ.get("DATR_MERGE_QPROJ", "1") != "0"   # A/B switch
-TILED_FORWARD = __import__("os").environ.get("DATR_MSDA_TILED_FWD", "0") == "1"
+PYR_FORWARD = __import__("os").environ.get("DATR_MSDA_PYR_FWD", "1") != "0"
 
 
 def _host_meta(shapes: torch.Tensor, lsi: torch.Tensor):
@@ -103,8 +102,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = _native.current_stream_ptr(value.device)
-        if sfx == "f32" and D == 32 and Lq == S and TILED_FORWARD:
-            # encoder self-attention: query-tiled forward, value windows staged in LDS
+        if sfx == "f32" and D == 32 and Lq == S and L == 4 and P == 4 and PYR_FORWARD:
+            # encoder self-attention: pyramid-region forward, coarse-level windows staged in LDS
             sh_host, ls_host = _host_meta(shapes, lsi)
             rc = _native.lib.datr_msda_forward_tiled_f32(
                 value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), sh_host.ctypes.data,

@@ -137,43 +137,17 @@ def pyramid_locs(shapes, N, Mh, P, spread, seed):
 
 
 @pytest.mark.parametrize("shapes,spread", [
-    ([(20, 27), (10, 14), (5, 7), (3, 4)], 1.5),      # ragged tiles on every level
-    ([(20, 27), (10, 14), (5, 7), (3, 4)], 12.0),     # offsets far beyond any window -> fallback
-    ([(33, 50), (17, 25)], 3.0),                      # L = 2, several tiles per level
-    ([(8, 16)], 0.5),                                 # exactly one full tile
-])
-def test_tiled_backward_for_pyramid_queries(M, O, dev, shapes, spread):
-    """Lq == S takes the query-tiled backward (LDS fixed-point accumulation + flush)."""
-    N, Mh, D, P = 2, 8, 32, 4
-    value, sh, lsi, _, attn = O.random_inputs(N, 1, Mh, D, shapes, P, seed=11)
-    S = value.shape[1]
-    loc = pyramid_locs(shapes, N, Mh, P, spread, seed=5)
-    g = torch.Generator().manual_seed(6)
-    attn = torch.softmax(torch.randn(N, S, Mh, len(shapes) * P, generator=g), -1).view(N, S, Mh, len(shapes), P)
-    go = torch.randn(N, S, Mh * D, generator=g) * 3.0
-    out, gv, gl, ga = run_hip(M, dev, value, sh, lsi, loc, attn, go)
-    torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
-    rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
-    scale = float(rv.abs().max())
-    # fixed-point step is ~3e-8 of max|grad_out| * sum|attn| per tile; hold to 2e-6 of the max
-    torch.testing.assert_close(gv, rv, rtol=1e-4, atol=2e-6 * scale)
-    torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
-    keep = off_grid(loc, sh, eps=1e-4)
-    torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
-    # zero grad_out -> exact zeros (scale = 0 path)
-    _, gv0, gl0, ga0 = run_hip(M, dev, value, sh, lsi, loc, attn, torch.zeros_like(go))
-    assert torch.count_nonzero(gv0) == 0 and torch.count_nonzero(gl0) == 0 and torch.count_nonzero(ga0) == 0
-
-
-@pytest.mark.parametrize("shapes,spread", [
     ([(20, 27), (10, 14), (5, 7), (3, 4)], 1.5),
     ([(20, 27), (10, 14), (5, 7), (3, 4)], 12.0),      # mostly out-of-window -> global fetches
-    ([(33, 50), (17, 25)], 3.0),
+    ([(40, 61), (20, 31), (10, 16), (5, 8)], 4.0),     # several regions per axis, ring-sized offsets
+    ([(33, 50), (17, 25), (9, 13), (5, 7)], 6.0),      # mixed: part in the windows, part outside
+    ([(33, 50), (17, 25)], 3.0),                       # 2 levels: not covered -> row kernel
 ])
-def test_tiled_forward_matches_oracle(M, O, dev, shapes, spread, monkeypatch):
-    """The experimental query-tiled forward (off by default, see datr_amd/msda.py) stays
-    parity-green: LDS-staged windows + out-of-window global fetches == oracle."""
-    monkeypatch.setattr(M, "TILED_FORWARD", True)
+def test_pyramid_region_forward_matches_oracle(M, O, dev, shapes, spread, monkeypatch):
+    """Encoder calls take csrc/msda_fwd_pyr.hip (coarse-level windows in LDS, level 0 and
+    out-of-window samples from global memory): == oracle, and == the row kernel up to the order
+    of the fp32 sums."""
+    assert M.PYR_FORWARD
     N, Mh, D, P = 2, 8, 32, 4
     value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, shapes, P, seed=13)
     S = value.shape[1]
@@ -182,9 +156,35 @@ def test_tiled_forward_matches_oracle(M, O, dev, shapes, spread, monkeypatch):
     attn = torch.softmax(torch.randn(N, S, Mh, len(shapes) * P, generator=g), -1).view(N, S, Mh, len(shapes), P)
     out = run_hip(M, dev, value, sh, lsi, loc, attn)
     torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
-    monkeypatch.setattr(M, "TILED_FORWARD", False)
+    monkeypatch.setattr(M, "PYR_FORWARD", False)
     rows = run_hip(M, dev, value, sh, lsi, loc, attn)
     torch.testing.assert_close(out, rows, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind", ["ring", "gauss", "uniform", "border"])
+def test_pyramid_region_forward_full_size_n4_against_oracle(M, O, dev, kind):
+    """The launch the training step actually makes -- N = 4 (source + target merged), the full
+    1333x800 pyramid, Lq = S = 22 223 -- against the C oracle on every element.
+    `ring`: pixel-centre reference points + the module's initial offset ring (what the encoder
+    produces at initialisation; every sample inside the windows); `gauss`: offsets ~ N(0, 2 px)
+    (a few per cent leave the windows); `uniform`: locations anywhere in the image (almost all
+    through the slow path); `border`: offsets ~ N(0, 12 px), many beyond the image edges."""
+    N, Mh, D, P = 4, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, FULL_SHAPES, P, seed=21)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(22)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    if kind == "uniform":
+        loc = torch.rand(N, S, Mh, 4, P, 2, generator=g) * 1.1 - 0.05
+    elif kind == "ring":
+        ring = M.MSDeformAttn(256, 4, Mh, P).sampling_offsets.bias.detach().view(1, 1, Mh, 4, P, 2)
+        wh = torch.tensor([[w, h] for h, w in FULL_SHAPES], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+        centres = pyramid_locs(FULL_SHAPES, N, Mh, P, 0.0, seed=23)
+        loc = (centres + ring / wh).contiguous()
+    else:
+        loc = pyramid_locs(FULL_SHAPES, N, Mh, P, 2.0 if kind == "gauss" else 12.0, seed=23)
+    out = run_hip(M, dev, value, sh, lsi, loc, attn)
+    torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
 
 
 def test_empty_and_fully_out_of_range(M, O, dev):

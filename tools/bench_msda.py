@@ -28,12 +28,12 @@ def bwd_bytes(N, S, Lq, M=8, D=32, K=16):
     return 4 * N * (2 * S * M * D + Lq * (M * D + 2 * M * K * 2 + 2 * M * K))
 
 
-def make_inputs(dev, Lq, dist, seed=3):
+def make_inputs(dev, Lq, dist, seed=3, N=2):
     g = torch.Generator(device="cpu").manual_seed(seed)
     shapes = torch.tensor(SHAPES, dtype=torch.int64)
     S = int(shapes.prod(1).sum())
     lsi = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
-    N, M, D, L, P = 2, 8, 32, 4, 4
+    M, D, L, P = 8, 32, 4, 4
     value = torch.rand(N, S, M, D, generator=g) * 0.01
     attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
     if dist == "uniform":
@@ -76,18 +76,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--dist", default="both")
+    ap.add_argument("--n", type=int, default=2, help="batch items per call (the training step merges source + target: 4)")
+    ap.add_argument("--fwd-only", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dists = ["uniform", "model"] if args.dist == "both" else [args.dist]
     for dist in dists:
         for Lq in (22223, 1100, 900):
-            value, sh, lsi, loc, attn = make_inputs(dev, Lq, dist)
+            value, sh, lsi, loc, attn = make_inputs(dev, Lq, dist, N=args.n)
             N, S = value.shape[0], value.shape[1]
             go = torch.randn(N, Lq, 256, device=dev)
             f = lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64)
             b = lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
             fm, fmin = time_fn(f, args.iters)
-            bm, bmin = time_fn(b, args.iters)
+            bm, bmin = (0.0, 0.0) if args.fwd_only else time_fn(b, args.iters)
             if os.environ.get("DATR_HIP_LIB", "").endswith("probe.so"):
                 import ctypes
                 from datr_amd import _native
@@ -102,11 +104,11 @@ def main():
                         ["maxgo", "A:geom", "win-zero", "B:gather+add", "B-barrier", "C:flush"], buf)),
                     f"total={tot / 1e6:.1f} Mcycles")
             print(json.dumps({
-                "dist": dist, "Lq": Lq,
+                "dist": dist, "Lq": Lq, "N": N, "pyr_fwd": msda.PYR_FORWARD,
                 "fwd_us_median": round(fm, 2), "fwd_us_min": round(fmin, 2),
                 "fwd_GBps": round(fwd_bytes(N, S, Lq) / fm / 1e3, 1),
                 "bwd_us_median": round(bm, 2), "bwd_us_min": round(bmin, 2),
-                "bwd_GBps": round(bwd_bytes(N, S, Lq) / bm / 1e3, 1)}), flush=True)
+                "bwd_GBps": round(bwd_bytes(N, S, Lq) / bm / 1e3, 1) if bm else None}), flush=True)
 
 
 if __name__ == "__main__":
