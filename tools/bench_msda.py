@@ -38,6 +38,17 @@ def make_inputs(dev, Lq, dist, seed=3, N=2):
     attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
     if dist == "uniform":
         loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    elif dist.startswith("gauss") and Lq == S:
+        # pixel-centre reference points + offsets ~ N(0, sigma px) in the target level
+        sigma = float(dist[5:] or 2.0)
+        refs = []
+        for h, w in SHAPES:
+            ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h,
+                                    torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+            refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+        ref = torch.cat(refs, 0).view(1, S, 1, 1, 1, 2)
+        wh = torch.tensor([[w, h] for h, w in SHAPES], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+        loc = (ref + torch.randn(N, Lq, M, L, P, 2, generator=g) * sigma / wh).contiguous()
     else:
         # reference points: pixel centres of the pyramid (encoder) or uniform boxes (decoder)
         if Lq == S:
@@ -102,6 +113,19 @@ def main():
                 print("phase cycles (thread 0 of every block, one bwd call): " + ", ".join(
                     f"{n}={100 * v / tot:.1f}%" for n, v in zip(
                         ["maxgo", "A:geom", "win-zero", "B:gather+add", "B-barrier", "C:flush"], buf)),
+                    f"total={tot / 1e6:.1f} Mcycles")
+            if os.environ.get("PYR_PROBE") and Lq == 22223:
+                import ctypes
+                from datr_amd import _native
+                buf = (ctypes.c_ulonglong * 8)()
+                _native.lib.datr_probe_pyr_phase_cycles(buf, 1)
+                f()
+                torch.cuda.synchronize()
+                _native.lib.datr_probe_pyr_phase_cycles(buf, 1)
+                tot = sum(buf) or 1
+                print("pyr phase cycles (lane 0 of every wave, one call): " + ", ".join(
+                    f"{n}={100 * v / tot:.1f}%" for n, v in zip(
+                        ["fill-issue", "fill-land", "barrier", "locwait+geom", "gathers", "slow+store", "tail-wait"], buf)),
                     f"total={tot / 1e6:.1f} Mcycles")
             print(json.dumps({
                 "dist": dist, "Lq": Lq, "N": N, "pyr_fwd": msda.PYR_FORWARD,
