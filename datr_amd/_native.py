@@ -47,6 +47,7 @@ _SIGNATURES = {
     "datr_box_loss_forward_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "datr_box_loss_backward_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "datr_sine_embed_f32": [_vp, _vp, _i64, _i64, _vp, _vp],
+    "datr_topk_rows_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "datr_gemm_k256_f32": [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp],
     "datr_conv3x3_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
                                       ctypes.c_float, _vp, _vp],

@@ -381,7 +381,8 @@ class PostProcess(nn.Module):
         logits, bbox = outputs["pred_logits"], outputs["pred_boxes"]
         assert len(logits) == len(target_sizes) and target_sizes.shape[1] == 2
         C = logits.shape[2]
-        scores, topk = torch.topk(logits.sigmoid().view(logits.shape[0], -1), self.num_select, dim=1)
+        from .fused import topk_rows
+        scores, topk = topk_rows(logits.sigmoid().view(logits.shape[0], -1), self.num_select)
         query_idx = torch.div(topk, C, rounding_mode="floor")
         labels = topk % C
         boxes = bbox if not_to_xyxy else box_ops.box_cxcywh_to_xyxy(bbox)

@@ -208,6 +208,34 @@ def add_layer_norm(x: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm)
     return norm(x + res)
 
 
+def topk_rows(scores: torch.Tensor, k: int):
+    """(values, indices) of the k largest entries of every row of `scores` [rows, n], sorted by
+    descending value, EQUAL values by ascending index (csrc/topk.hip): one total order, so the
+    selection does not depend on device or launch -- `torch.topk` leaves the order, and at the
+    k-th value the membership, of ties open (its CPU and GPU implementations differ).  With
+    distinct scores this IS torch.topk's result.  On the CPU (host-side tests only: the product
+    runs on the device) the same order comes from a stable sort."""
+    assert scores.dim() == 2 and 1 <= k <= scores.shape[1]
+    if not scores.is_cuda:
+        key = scores.float()
+        key = torch.where(torch.isnan(key), torch.full_like(key, float("inf")), key)
+        order = torch.argsort(key, dim=1, descending=True, stable=True)
+        nan_first = torch.argsort((~torch.isnan(scores.float())).to(torch.int8).gather(1, order), dim=1, stable=True)
+        idx = order.gather(1, nan_first)[:, :k]
+        return scores.gather(1, idx), idx
+    if k > 1024:
+        raise NotImplementedError("topk_rows: k <= 1024 on the device (csrc/topk.hip)")
+    x = scores.detach().float().contiguous()
+    rows, n = x.shape
+    idx = torch.empty(rows, k, dtype=torch.int64, device=x.device)
+    val = torch.empty(rows, k, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _native.lib.datr_topk_rows_f32(x.data_ptr(), rows, n, k, idx.data_ptr(), val.data_ptr(),
+                                            _native.current_stream_ptr(x.device))
+    _native.check(rc, "topk_rows")
+    return scores.gather(1, idx) if scores.requires_grad or scores.dtype != torch.float32 else val, idx
+
+
 def column_sums(x2: torch.Tensor) -> torch.Tensor:
     """sum over rows of a contiguous [rows, cols] fp32 device matrix (cols % 4 == 0)."""
     rows, cols = x2.shape

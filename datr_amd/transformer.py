@@ -508,10 +508,14 @@ class DeformableTransformer(nn.Module):
 
     def select_queries(self, scores: Tensor) -> Tensor:
         """Indices [N, num_queries] of the highest-scoring encoder tokens
-        (deformable_transformer.py:342).  A method of its own because it is THE discontinuity
-        of the forward pass: parity tests pin it as a function and may substitute the
-        reference's selection when comparing what comes after it."""
-        return torch.topk(scores, self.num_queries, dim=1)[1]
+        (deformable_transformer.py:342: `torch.topk(scores, num_queries, dim=1)[1]`), in ONE
+        defined order -- descending score, equal scores by ascending token index
+        (`fused.topk_rows`, csrc/topk.hip) -- because `torch.topk` fixes neither the order nor,
+        at the 900th score, the membership of ties.  A method of its own because it is THE
+        discontinuity of the forward pass: parity tests pin it as a function and may substitute
+        the reference's selection when comparing what comes after it."""
+        from .fused import topk_rows
+        return topk_rows(scores, self.num_queries)[1]
 
     @staticmethod
     def get_valid_ratio(mask):

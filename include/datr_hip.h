@@ -246,6 +246,18 @@ int datr_box_loss_backward_f32(const float *src, const float *tgt, const int64_t
                                void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Deterministic row-wise top-k, k <= 1024 (csrc/topk.hip): the two-stage query selection
+ * `torch.topk(enc_outputs_class_unselected.max(-1)[0], 900, dim=1)[1]`
+ * (/root/reference/models/dino/deformable_transformer.py:342) and PostProcess's
+ * `torch.topk(prob.view(B, -1), num_select, dim=1)` (/root/reference/models/dino/dino.py:960).
+ * scores [rows, n] fp32 -> out_idx [rows, k] int64, out_val [rows, k] fp32 (may be NULL), sorted by
+ * descending score, equal scores by ascending index, NaN first: one total order, so the result
+ * does not depend on the device or the launch (torch.topk leaves the order of ties open).
+ * k > 1024: DATR_EUNSUPPORTED. */
+int datr_topk_rows_f32(const float *scores, int64_t rows, int64_t n, int64_t k, int64_t *out_idx,
+                       float *out_val, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Sine embedding of the decoder's reference boxes: `gen_sineembed_for_position`
  * (/root/reference/models/dino/utils.py:138-163).  pos [rows, ncoord] (ncoord = 2: (x, y) or
  * 4: (x, y, w, h)), dim_t [128] = 10000^(2 floor(k / 2) / 128), out [rows, 128 * ncoord] in the

@@ -87,13 +87,14 @@ def main():
     criterion.train()
     samples = ref_nest(imgs)
     torch.manual_seed(123)
-    topk_calls = []
+    topk_calls, topk_inputs = [], []
     real_topk = torch.topk
 
     def rec_topk(inp, k, *a, **kw):
         res = real_topk(inp, k, *a, **kw)
         if k == 900:
             topk_calls.append(res[1].clone())
+            topk_inputs.append(inp.detach().clone())      # the scores the selection is made from
         return res
     torch.topk = rec_topk
     try:
@@ -114,6 +115,7 @@ def main():
         # the reference draws {0,1} and maps to {-1,+1} afterwards (dn_components.py:84)
         "noise_rand_sign": to_np(rec.draws[2] * 2.0 - 1.0), "noise_rand_part": to_np(rec.draws[3]),
         "topk_source": to_np(topk_calls[0]), "topk_target": to_np(topk_calls[1]),
+        "topk_scores_source": to_np(topk_inputs[0]), "topk_scores_target": to_np(topk_inputs[1]),
         "pred_logits": to_np(out["pred_logits"]), "pred_boxes": to_np(out["pred_boxes"]),
         "aux_logits": to_np(torch.stack([a["pred_logits"] for a in out["aux_outputs"]])),
         "aux_boxes": to_np(torch.stack([a["pred_boxes"] for a in out["aux_outputs"]])),
