@@ -235,10 +235,11 @@ def test_full_size_step_matches_host_run_with_oracle_msda(monkeypatch):
         m.transformer.select_queries = select
         samples = nested_tensor_from_tensor_list([i.to(device) for i in imgs])
         tg = [{k: v.to(device) for k, v in t_.items()} for t_ in targets]
-        with torch.no_grad():
-            out = m(samples, tg)
-            losses = criterion(out, tg)
-        return out, {k: float(v) for k, v in losses.items()}, picked
+        out = m(samples, tg)                   # (the criterion insists on graph-attached inputs)
+        losses = criterion(out, tg)
+        out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+        out["da_output"] = {"backbone_DA": out["da_output"]["backbone_DA"].detach()}
+        return out, {k: float(v.detach()) for k, v in losses.items()}, picked
 
     out_d, loss_d, picked = run(model, dev)
     assert all(np.isfinite(v) for v in loss_d.values()) and len(loss_d) == 82

@@ -187,6 +187,34 @@ def test_pyramid_region_forward_full_size_n4_against_oracle(M, O, dev, kind):
     torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
 
 
+@pytest.mark.parametrize("kind", ["ring", "gauss"])
+def test_encoder_backward_full_size_n4_against_oracle(M, O, dev, kind):
+    """The backward launch of the training step's merged encoder pass -- N = 4, Lq = S = 22 223,
+    query-tiled kernel (csrc/msda_bwd_tiled.hip) -- against the C oracle on EVERY element
+    (the full-size call was only compared with the build's own fp64 kernels)."""
+    N, Mh, D, P = 4, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, FULL_SHAPES, P, seed=31)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(32)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    if kind == "ring":
+        ring = M.MSDeformAttn(256, 4, Mh, P).sampling_offsets.bias.detach().view(1, 1, Mh, 4, P, 2)
+        wh = torch.tensor([[w, h] for h, w in FULL_SHAPES], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+        # a little noise: on the exact ring most samples sit ON grid lines, where d/d(loc) jumps
+        loc = (pyramid_locs(FULL_SHAPES, N, Mh, P, 0.05, seed=33) + ring / wh).contiguous()
+    else:
+        loc = pyramid_locs(FULL_SHAPES, N, Mh, P, 3.0, seed=33)
+    go = torch.randn(N, S, Mh * D, generator=g)
+    out, gv, gl, ga = run_hip(M, dev, value, sh, lsi, loc, attn, go)
+    torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
+    rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
+    scale = float(rv.abs().max())
+    torch.testing.assert_close(gv, rv, rtol=1e-3, atol=1e-5 * scale)
+    torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
+    keep = off_grid(loc, sh)
+    torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
+
+
 def test_empty_and_fully_out_of_range(M, O, dev):
     value, sh, lsi, loc, attn = O.random_inputs(1, 0, 8, 32, [(4, 4)], 4, seed=1)
     assert run_hip(M, dev, value, sh, lsi, loc, attn).shape == (1, 0, 256)
