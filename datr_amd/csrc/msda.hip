@@ -673,6 +673,15 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
     if (hipMemsetAsync(grad_value, 0, (size_t)(N * S * M * D) * sizeof(float),
                        (hipStream_t)stream) != hipSuccess)
         return DATR_ELAUNCH;
+    // encoder calls: pyramid regions, grad_value by sorted scatter (msda_bwd_pyr.hip);
+    // DATR_MSDA_PYR_BWD=0 keeps the query-tiled kernel (A/B measurements)
+    static const bool pyr_bwd = !(getenv("DATR_MSDA_PYR_BWD") && atoi(getenv("DATR_MSDA_PYR_BWD")) == 0);
+    if (Lq == S && pyr_bwd) {
+        const int rc = datr_internal_msda_bwd_pyr_d32(grad_out, value, loc, attn, shapes_host,
+                                                      level_start_host, N, S, M, D, L, Lq, P,
+                                                      grad_value, grad_loc, grad_attn, stream);
+        if (rc != DATR_EUNSUPPORTED) return rc;
+    }
     return datr_internal_msda_bwd_tiled_d32(grad_out, value, loc, attn, &meta, N, S, M, P,
                                             grad_value, grad_loc, grad_attn, stream);
 }

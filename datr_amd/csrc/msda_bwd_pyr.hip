@@ -1,0 +1,381 @@
+// msda_bwd_pyr.hip -- MSDA backward for the encoder calls (Lq == S, D == 32, L == P == 4),
+// pyramid-region decomposition (msda_pyr.h), grad_value by SORTED SCATTER instead of LDS atomics.
+//
+// Reference behaviour: /root/reference/models/dino/ops/src/cuda/ms_deform_im2col_cuda.cuh:301-403
+// (col2im: grad_value += w * a * grad_out at the 4 corners, grad_attn = <grad_out, bilinear(value)>,
+// grad_loc = a * {W, H} * <grad_out, d bilinear / d (w, h)>), host :87-159.
+//
+// Why.  The query-tiled kernel (msda_bwd_tiled.hip) accumulates d out / d value in LDS with
+// fixed-point ds_add_u64: 728 M lane-adds per N=4 encoder call at 2.45 lane-ops/clk/CU are half
+// of its 0.97 ms (profiles/r01_probes.md), and its 16 x 8 tiles flush 14.6 window rows per query
+// with float atomics (2.8-3.8x the algorithmic write traffic).  Here:
+//   * a 768-thread workgroup owns one (image, region, head): all queries of a region of about
+//     12 x 28 level-0 pixels in all four levels (<= 512 queries), i.e. 4 window rows per query;
+//   * per level the 16 corner contributions of every query are written as 8-byte records
+//     {weight = corner weight x attention, query slot} into LDS, COUNTING-SORTED by destination
+//     row of the level's window: one 32-bit LDS atomic per record for the histogram and one for
+//     the cursor (2 per corner instead of 32 channel adds);
+//   * a row's gradient is then a GATHER: 8 lanes walk the row's contiguous records and
+//     accumulate weight x grad_out[slot] in registers from the workgroup's LDS copy of its
+//     queries' grad_out rows (ds_read_b128, no atomics), and add the finished row to grad_value
+//     with one 128-byte-coalesced float atomic pass (windows of neighbouring regions overlap);
+//   * grad_attn / grad_loc come from the corner rows gathered with zero-filling buffer loads
+//     as before; lane roles as in msda_fwd_pyr.hip: 4 lanes share a query, lane p works out
+//     point p's geometry, a quad covers a 128-B row with two 64-B halves, dot products are
+//     completed with two DPP steps inside the quad.
+// A sample whose corners fall outside the level's window (offsets beyond the halo) bypasses the
+// sort: its contributions go to grad_value as plain float atomics -- results never depend on
+// the window heuristic.  grad_value must arrive zero-filled (the C entry point memsets it).
+// The order of a row's records depends on LDS atomic arrival, so grad_value is reproducible to
+// fp32 rounding, not bitwise (the reference's atomicAdd is no different).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "datr_hip.h"
+#include "msda_pyr.h"
+
+namespace {
+
+constexpr int kThreads = 768;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxQ = 512;                 // queries of a region
+constexpr int kMaxRows = 1024;             // rows of a level's window
+constexpr int kMaxTasks = (kMaxQ / 16 + kWaves - 1) / kWaves;      // 16-query tasks per wave: 3
+constexpr unsigned kOutOfRange = 0x80000000u;
+constexpr int kRowBytes = 128;
+
+// LDS map (bytes)
+constexpr int kGoOff = 0;                                  // grad_out rows by query slot
+constexpr int kRecOff = kGoOff + kMaxQ * kRowBytes;        // records of the current level
+constexpr int kHistOff = kRecOff + kMaxQ * 16 * 8;         // counts -> exclusive offsets [rows + 1]
+constexpr int kCurOff = kHistOff + (2 * kThreads) * 4;     // cursors
+constexpr int kTabOff = kCurOff + (2 * kThreads) * 4;      // query slot -> pyramid index
+constexpr int kScanOff = kTabOff + kMaxQ * 4;              // per-wave totals of the scan
+constexpr int kLdsBytes = kScanOff + 64;
+static_assert(kMaxRows + 1 <= 2 * kThreads, "the scan gives every thread two histogram entries");
+static_assert(kLdsBytes <= 160 * 1024, "LDS");
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ f4 load_row4(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    static_assert(sizeof(r) == 16, "b128");
+    return __builtin_bit_cast(f4, r);
+}
+template <int SRC>
+__device__ __forceinline__ int quad_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, SRC * 0x55, 0xF, 0xF, true);
+}
+template <int SRC>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, quad_bcast<SRC>(__builtin_bit_cast(int, v)));
+}
+// sum over the 4 lanes of a quad; every lane ends with the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+__device__ __forceinline__ float dot4(const f4 a, const f4 b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// geometry of one sample, kept in registers between the counting and the filling pass
+struct Sample {
+    int yx;            // (iy << 16) | (ix & 0xffff): top-left corner pixel
+    float lh, lw, a;
+    int flags;         // bits 0..3 corner validity (tl, tr, bl, br), bit 4: all corners in the window
+    int row;           // window row index of the top-left corner (when bit 4)
+};
+
+__global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const float *__restrict__ loc, const float *__restrict__ attn, const PyrMeta pm, int S, int M,
+    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    unsigned *hist = reinterpret_cast<unsigned *>(lds + kHistOff);
+    unsigned *cur = reinterpret_cast<unsigned *>(lds + kCurOff);
+    int *qtab = reinterpret_cast<int *>(lds + kTabOff);
+    unsigned *scan = reinterpret_cast<unsigned *>(lds + kScanOff);
+    unsigned long long *recs = reinterpret_cast<unsigned long long *>(lds + kRecOff);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int m = bid % M;
+    const int reg = (bid / M) % (pm.nRy * pm.nRx);
+    const int n = bid / (M * pm.nRy * pm.nRx);
+    const int ry = reg / pm.nRx, rx = reg % pm.nRx;
+    const unsigned row_stride = (unsigned)M * kRowBytes;
+    const size_t Lq = (size_t)S;
+
+    const size_t item = ((size_t)n * S * M + m) * 32;
+    const int records = (S * M - m) * kRowBytes;
+    const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(value + item), 0, records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc =
+        __builtin_amdgcn_make_buffer_rsrc(grad_value + item, 0, records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(grad_out + item), 0, records, 0x00020000);
+
+    // ---- the region's queries; their grad_out rows (this head) into LDS by LDS-DMA -------------
+    int pre[5];
+    pre[0] = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+        pre[l + 1] = pre[l] + (pm.yb[l][ry + 1] - pm.yb[l][ry]) * (pm.xb[l][rx + 1] - pm.xb[l][rx]);
+    const int nq = pre[4];
+    auto decode = [&](int qi) {
+        const int lq = (qi >= pre[1]) + (qi >= pre[2]) + (qi >= pre[3]);
+        const int li = qi - (lq == 0 ? 0 : lq == 1 ? pre[1] : lq == 2 ? pre[2] : pre[3]);
+        const int oy = pm.yb[lq][ry], ox = pm.xb[lq][rx];
+        const int rw = pm.xb[lq][rx + 1] - ox;
+        const int r_ = (int)(((float)li + 0.5f) / (float)rw);
+        return pm.start[lq] + (oy + r_) * pm.W[lq] + ox + (li - r_ * rw);
+    };
+    for (int qi = tid; qi < nq; qi += kThreads) qtab[qi] = decode(qi);
+    for (int s0 = wave * 8; s0 < nq; s0 += kWaves * 8) {           // 8 query rows per instruction
+        const int slot_ = s0 + (lane >> 3);
+        const unsigned off = slot_ < nq ? (unsigned)decode(slot_) * row_stride + (unsigned)(lane & 7) * 16u
+                                        : kOutOfRange;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(osrc, reinterpret_cast<lds_void *>(kGoOff + s0 * kRowBytes),
+                                                 16, (int)off, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // lane roles (as in msda_fwd_pyr.hip): 4 lanes per query, lane j = point j's geometry and the
+    // 16-B pieces 16 j / 16 j + 64 of every row
+    const int slot = lane >> 2, j = lane & 3;
+    const int chan = 16 * j + 64 * (slot & 1), chan2 = chan ^ 64;
+    const int ntasks = (nq + 15) >> 4;
+
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        const int Hl = pm.H[l], Wl = pm.W[l], stl = pm.start[l];
+        const int WW = pm.WW[l], WH = pm.WH[l], rows = WW * WH;
+        const int wy0 = pm.wy0[l][ry], wx0 = pm.wx0[l][rx];
+        const float Hf = (float)Hl, Wf = (float)Wl;
+
+        for (int i = tid; i <= rows; i += kThreads) hist[i] = 0;
+        __syncthreads();
+
+        // ---- pass A: geometry of point j of this lane's queries; count records per window row ---
+        Sample smp[kMaxTasks];
+#pragma unroll
+        for (int k = 0; k < kMaxTasks; ++k) {
+            const int t = wave + k * kWaves;
+            Sample s;
+            s.yx = 0; s.lh = 0.f; s.lw = 0.f; s.a = 0.f; s.flags = 0; s.row = 0;
+            const int qi = t * 16 + slot;
+            if (t < ntasks && qi < nq) {
+                const size_t idx = (((size_t)n * Lq + qtab[qi]) * M + m) * 16 + l * 4 + j;
+                const f2 xy = reinterpret_cast<const f2 *>(loc)[idx];
+                s.a = attn[idx];
+                const float h_im = xy.y * Hf - 0.5f, w_im = xy.x * Wf - 0.5f;
+                const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+                if (inside) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int iy = (int)hf, ix = (int)wf;
+                    s.lh = h_im - hf;
+                    s.lw = w_im - wf;
+                    s.yx = (iy << 16) | (ix & 0xffff);
+                    const bool top = iy >= 0, bot = iy + 1 <= Hl - 1, lef = ix >= 0, rig = ix + 1 <= Wl - 1;
+                    s.flags = (top && lef ? 1 : 0) | (top && rig ? 2 : 0) | (bot && lef ? 4 : 0) |
+                              (bot && rig ? 8 : 0);
+                    const int wy = iy - wy0, wx = ix - wx0;
+                    if ((unsigned)wy <= (unsigned)(WH - 2) && (unsigned)wx <= (unsigned)(WW - 2)) {
+                        s.flags |= 16;
+                        s.row = wy * WW + wx;
+                        if (s.flags & 1) atomicAdd(&hist[s.row], 1u);
+                        if (s.flags & 2) atomicAdd(&hist[s.row + 1], 1u);
+                        if (s.flags & 4) atomicAdd(&hist[s.row + WW], 1u);
+                        if (s.flags & 8) atomicAdd(&hist[s.row + WW + 1], 1u);
+                    }
+                }
+            }
+            smp[k] = s;
+        }
+        __syncthreads();
+
+        // ---- exclusive scan of the counts (two entries per thread) ------------------------------
+        {
+            const int i0 = 2 * tid, i1 = i0 + 1;
+            const unsigned c0 = i0 <= rows ? hist[i0] : 0u, c1 = i1 <= rows ? hist[i1] : 0u;
+            unsigned incl = c0 + c1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            if (lane == 63) scan[wave] = incl;
+            __syncthreads();
+            unsigned base = 0;
+            for (int w = 0; w < wave; ++w) base += scan[w];
+            const unsigned excl = base + incl - (c0 + c1);
+            if (i0 <= rows) { hist[i0] = excl; cur[i0] = excl; }
+            if (i1 <= rows) { hist[i1] = excl + c0; cur[i1] = excl + c0; }
+        }
+        __syncthreads();
+
+        // ---- pass B: records, grad_attn / grad_loc ----------------------------------------------
+#pragma unroll
+        for (int k = 0; k < kMaxTasks; ++k) {
+            const int t = wave + k * kWaves;
+            if (t >= ntasks) break;                                   // wave-uniform
+            const Sample s = smp[k];
+            const int qi = t * 16 + slot;
+            const bool live = qi < nq;
+            const int qslot = live ? qi : nq - 1;
+            const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+            const float c0 = hh * hw, c1 = hh * s.lw, c2 = s.lh * hw, c3 = s.lh * s.lw;
+            const int iy = s.yx >> 16, ix = (int)(short)(s.yx & 0xffff);
+            const unsigned pix = (unsigned)(stl + iy * Wl + ix) * row_stride;
+            if (live && (s.flags & 16)) {
+                const unsigned lo = (unsigned)qslot;
+#define DATR_REC(BIT, ROW, C)                                                                    \
+                if (s.flags & (BIT)) {                                                           \
+                    const unsigned pos = atomicAdd(&cur[ROW], 1u);                               \
+                    recs[pos] = ((unsigned long long)__float_as_uint((C) * s.a) << 32) | lo;      \
+                }
+                DATR_REC(1, s.row, c0)
+                DATR_REC(2, s.row + 1, c1)
+                DATR_REC(4, s.row + WW, c2)
+                DATR_REC(8, s.row + WW + 1, c3)
+#undef DATR_REC
+            } else if (live && (s.flags & 15)) {
+                // outside the window: this lane adds its sample's contributions itself
+                const f4 *gq = reinterpret_cast<const f4 *>(lds + kGoOff + qslot * kRowBytes);
+#define DATR_DIRECT(BIT, OFF, C)                                                                 \
+                if (s.flags & (BIT)) {                                                           \
+                    const float w_ = (C) * s.a;                                                  \
+                    for (int c = 0; c < 8; ++c) {                                                \
+                        const f4 g_ = gq[c];                                                     \
+                        const unsigned o_ = pix + (OFF) + (unsigned)c * 16u;                     \
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w_ * g_.x, gsrc, o_, 0, 0);       \
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w_ * g_.y, gsrc, o_ + 4, 0, 0);   \
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w_ * g_.z, gsrc, o_ + 8, 0, 0);   \
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w_ * g_.w, gsrc, o_ + 12, 0, 0);  \
+                    }                                                                            \
+                }
+                DATR_DIRECT(1, 0u, c0)
+                DATR_DIRECT(2, row_stride, c1)
+                DATR_DIRECT(4, (unsigned)Wl * row_stride, c2)
+                DATR_DIRECT(8, (unsigned)(Wl + 1) * row_stride, c3)
+#undef DATR_DIRECT
+            }
+
+            // corner offsets of this lane's sample (out-of-image corners read zeros)
+            int g[4];
+            g[0] = (int)((s.flags & 1) ? pix : kOutOfRange);
+            g[1] = (int)((s.flags & 2) ? pix + row_stride : kOutOfRange);
+            g[2] = (int)((s.flags & 4) ? pix + (unsigned)Wl * row_stride : kOutOfRange);
+            g[3] = (int)((s.flags & 8) ? pix + (unsigned)(Wl + 1) * row_stride : kOutOfRange);
+            // this quad's grad_out row: the lane's two 16-B pieces
+            const f4 go0 = *reinterpret_cast<const f4 *>(lds + kGoOff + qslot * kRowBytes + chan);
+            const f4 go1 = *reinterpret_cast<const f4 *>(lds + kGoOff + qslot * kRowBytes + chan2);
+
+            float pa = 0.f, pw = 0.f, ph = 0.f;          // results of THIS lane's sample
+#define DATR_POINT(SRC)                                                                          \
+            {                                                                                    \
+                float d[4];                                                                      \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                  \
+                    const int o1 = quad_bcast<SRC>(g[c]) + chan, o2 = quad_bcast<SRC>(g[c]) + chan2; \
+                    d[c] = dot4(go0, load_row4(vsrc, (unsigned)o1)) + dot4(go1, load_row4(vsrc, (unsigned)o2)); \
+                }                                                                                \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) d[c] = quad_sum(d[c]);             \
+                if (j == (SRC)) {                                                                \
+                    pa = c0 * d[0] + c1 * d[1] + c2 * d[2] + c3 * d[3];                           \
+                    pw = hh * (d[1] - d[0]) + s.lh * (d[3] - d[2]);                               \
+                    ph = hw * (d[2] - d[0]) + s.lw * (d[3] - d[1]);                               \
+                }                                                                                \
+            }
+            DATR_POINT(0)
+            DATR_POINT(1)
+            DATR_POINT(2)
+            DATR_POINT(3)
+#undef DATR_POINT
+            if (live) {
+                const size_t idx = (((size_t)n * Lq + qtab[qslot]) * M + m) * 16 + l * 4 + j;
+                grad_attn[idx] = pa;
+                reinterpret_cast<f2 *>(grad_loc)[idx] = f2{pw * s.a * Wf, ph * s.a * Hf};
+            }
+        }
+        __syncthreads();
+
+        // ---- reduce: a window row's gradient is a gather over its records -----------------------
+        {
+            const int grp = tid >> 3, c8 = tid & 7;
+            for (int r = grp; r < rows; r += kThreads / 8) {
+                const unsigned beg = hist[r], end = hist[r + 1];
+                if (beg == end) continue;
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                // four records in flight: record read -> grad_out row read -> FMA is a chain of
+                // two LDS latencies, so the loop is unrolled to keep several chains going
+                for (unsigned e = beg; e < end; e += 4) {
+                    unsigned long long rec[4];
+                    f4 g_[4];
+                    float w_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rec[u] = recs[min(e + u, end - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        w_[u] = e + u < end ? __uint_as_float((unsigned)(rec[u] >> 32)) : 0.f;
+                        g_[u] = *reinterpret_cast<const f4 *>(
+                            lds + kGoOff + (int)(rec[u] & 0xffffffffull) * kRowBytes + c8 * 16);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc.x = fmaf(w_[u], g_[u].x, acc.x);
+                        acc.y = fmaf(w_[u], g_[u].y, acc.y);
+                        acc.z = fmaf(w_[u], g_[u].z, acc.z);
+                        acc.w = fmaf(w_[u], g_[u].w, acc.w);
+                    }
+                }
+                const int wy = r / WW, wx = r - wy * WW;
+                const unsigned o_ = (unsigned)(stl + (wy0 + wy) * Wl + wx0 + wx) * row_stride + (unsigned)c8 * 16u;
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.x, gsrc, o_, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.y, gsrc, o_ + 4, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.z, gsrc, o_ + 8, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.w, gsrc, o_ + 12, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
+// grad_value must be zero-filled by the caller.
+extern "C" int datr_internal_msda_bwd_pyr_d32(
+    const float *grad_out, const float *value, const float *loc, const float *attn,
+    const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value, float *grad_loc,
+    float *grad_attn, void *stream)
+{
+    if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || N < 1) return DATR_EUNSUPPORTED;
+    static const float halo = pyr_halo_from_env();
+    PyrMeta pm;
+    const auto fits = [](const PyrMeta &m_, int most_queries) {
+        int rows = 0;
+        for (int l = 0; l < 4; ++l) rows = std::max(rows, m_.WH[l] * m_.WW[l]);
+        return rows <= kMaxRows && most_queries <= kMaxQ;
+    };
+    if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, 12.5, 28.0, fits))
+        return DATR_EUNSUPPORTED;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    kLdsBytes) == hipSuccess;
+    if (!attr_ok) return DATR_EUNSUPPORTED;
+    const long blocks = (long)N * pm.nRy * pm.nRx * M;
+    if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
+    hipLaunchKernelGGL(msda_bwd_pyr_d32, dim3((unsigned)blocks), dim3(kThreads), (size_t)kLdsBytes,
+                       (hipStream_t)stream, grad_out, value, loc, attn, pm, (int)S, (int)M, grad_value,
+                       grad_loc, grad_attn);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}

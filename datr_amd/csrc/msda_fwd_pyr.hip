@@ -54,6 +54,7 @@
 #include <cstdlib>
 
 #include "datr_hip.h"
+#include "msda_pyr.h"
 
 // Development only (tools/probes/pyr_ablate.sh): compile pieces out to see what they cost.
 // 1 = no window fill, 2 = no level-0 (vector-memory) gathers, 4 = no LDS gathers,
@@ -97,20 +98,10 @@ namespace {
 constexpr int kThreads = PYR_THREADS;
 constexpr int kWaves = kThreads / 64;
 constexpr int kGlobalInFlight = PYR_GIF;        // level-0 samples in flight beside the LDS gathers
-constexpr int kMaxR = 16;                        // regions per axis
 constexpr unsigned kOutOfRange = 0x80000000u;    // >= num_records of every descriptor built here
 constexpr int kRowBytes = 128;                   // D = 32 floats
 constexpr int kMaxLds = 156 * 1024;              // windows + query table
 constexpr int kMaxQueries = 2048;                // query-table entries (8 KiB)
-
-struct PyrMeta {
-    int H[4], W[4], start[4];
-    int nRy, nRx;
-    int WH[4], WW[4], lds_base[4];               // windows of levels 1..3 ([0] unused), bytes
-    int lds_bytes;
-    short yb[4][kMaxR + 1], xb[4][kMaxR + 1];    // query rows / cols of level l in region i: [b[i], b[i+1])
-    short wy0[4][kMaxR], wx0[4][kMaxR];          // window origin (may be negative: zero apron)
-};
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -549,98 +540,6 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_pyr_d32(
 #endif
 }
 
-// ceil(a / b) for b > 0 and any a
-inline long ceil_div(long a, long b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); }
-
-bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, int64_t S, float halo) {
-    long total = 0;
-    for (int l = 0; l < 4; ++l) {
-        const long H = sh[2 * l], W = sh[2 * l + 1];
-        if (H < 1 || W < 1 || H > 4096 || W > 4096 || ls[l] != total) return false;
-        pm.H[l] = (int)H; pm.W[l] = (int)W; pm.start[l] = (int)total;
-        total += H * W;
-    }
-    if (total != S || S * 8 * 128 >= (1L << 31)) return false;
-    // level l must be the coarser the larger l (windows are sized for a pyramid)
-    for (int l = 1; l < 4; ++l)
-        if (pm.H[l] > pm.H[l - 1] || pm.W[l] > pm.W[l - 1]) return false;
-    const int H0 = pm.H[0], W0 = pm.W[0];
-    int nRy = std::min(kMaxR, std::max(1, (int)std::lround(H0 / 16.7)));
-    int nRx = std::min(kMaxR, std::max(1, (int)std::lround(W0 / 41.75)));
-    if (const char *e = std::getenv("DATR_MSDA_PYR_REGIONS")) {          // development: "RYxRX"
-        int a = 0, b = 0;
-        if (std::sscanf(e, "%dx%d", &a, &b) == 2 && a >= 1 && b >= 1 && a <= kMaxR && b <= kMaxR) {
-            nRy = a; nRx = b;
-        }
-    }
-    for (;;) {
-        pm.nRy = nRy; pm.nRx = nRx;
-        for (int axis = 0; axis < 2; ++axis) {
-            const int nR = axis ? nRx : nRy;
-            const int *dim = axis ? pm.W : pm.H;
-            short (*qb)[kMaxR + 1] = axis ? pm.xb : pm.yb;
-            short (*w0)[kMaxR] = axis ? pm.wx0 : pm.wy0;
-            int *wdim = axis ? pm.WW : pm.WH;
-            const long D0 = dim[0];
-            for (int l = 0; l < 4; ++l) {
-                for (int i = 0; i <= nR; ++i) {
-                    const long b0 = (long)i * D0 / nR;                 // level-0 boundary
-                    // first pixel of level l whose centre (y + 0.5) / D_l >= b0 / D0
-                    long y = ceil_div(2 * b0 * dim[l] - D0, 2 * D0);
-                    y = std::min<long>(std::max<long>(y, 0), dim[l]);
-                    qb[l][i] = (short)(i == nR ? dim[l] : y);
-                }
-            }
-            for (int l = 1; l < 4; ++l) {
-                int widest = 2;
-                for (int i = 0; i < nR; ++i) {
-                    double lo = 1e30, hi = -1e30;
-                    for (int lq = 0; lq < 4; ++lq) {
-                        if (qb[lq][i + 1] <= qb[lq][i]) continue;
-                        lo = std::min(lo, (qb[lq][i] + 0.5) / dim[lq] * dim[l] - 0.5);
-                        hi = std::max(hi, (qb[lq][i + 1] - 0.5) / dim[lq] * dim[l] - 0.5);
-                    }
-                    if (lo > hi) { lo = hi = 0; }
-                    const int a = (int)std::floor(lo - halo), b = (int)std::floor(hi + halo) + 1;
-                    w0[l][i] = (short)a;
-                    widest = std::max(widest, b - a + 1);
-                }
-                wdim[l] = widest;
-            }
-        }
-        int bytes = 0;
-        for (int l = 1; l < 4; ++l) {
-            pm.lds_base[l] = bytes;
-            // whole 1 KiB LDS-DMA pieces: the zero-filled tail lanes of a level's last piece must
-            // not land in the next level's window
-            bytes += (pm.WH[l] * pm.WW[l] * kRowBytes + 1023) & ~1023;
-        }
-        pm.lds_base[0] = 0; pm.WH[0] = pm.WW[0] = 0;
-        if (std::getenv("DATR_MSDA_PYR_ALIAS")) {     // development, WRONG results: all windows share
-            bytes = 0;                                // one LDS area (what would 2 workgroups/CU buy?)
-            for (int l = 1; l < 4; ++l) {
-                pm.lds_base[l] = 0;
-                bytes = std::max(bytes, (pm.WH[l] * pm.WW[l] * kRowBytes + 1023) & ~1023);
-            }
-        }
-        pm.lds_bytes = bytes;
-        int most = 0;                              // queries of the largest region
-        for (int i = 0; i < nRy; ++i)
-            for (int k = 0; k < nRx; ++k) {
-                int c = 0;
-                for (int l = 0; l < 4; ++l)
-                    c += (pm.yb[l][i + 1] - pm.yb[l][i]) * (pm.xb[l][k + 1] - pm.xb[l][k]);
-                most = std::max(most, c);
-            }
-        if (bytes + 4 * kMaxQueries <= kMaxLds && most <= kMaxQueries) return true;
-        // too large: more, smaller regions along the longer region side
-        if ((double)H0 / nRy >= (double)W0 / nRx && nRy < kMaxR) ++nRy;
-        else if (nRx < kMaxR) ++nRx;
-        else if (nRy < kMaxR) ++nRy;
-        else return false;
-    }
-}
-
 }  // namespace
 
 // Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
@@ -650,13 +549,28 @@ extern "C" int datr_internal_msda_fwd_pyr_d32(
     int64_t Lq, int64_t P, float *out, void *stream)
 {
     if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || N < 1) return DATR_EUNSUPPORTED;
-    static const float halo = [] {
-        const char *e = std::getenv("DATR_MSDA_PYR_HALO");
-        const float h = e ? (float)std::atof(e) : 4.5f;
-        return h >= 0.5f && h <= 16.f ? h : 4.5f;
-    }();
+    static const float halo = pyr_halo_from_env();
     PyrMeta pm;
-    if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo)) return DATR_EUNSUPPORTED;
+    // regions of about 17 x 42 level-0 pixels (6 x 4 at 1333x800), shrunk until the windows of
+    // levels 1..3 and the query table fit the LDS
+    const auto fits = [](const PyrMeta &m_, int most_queries) {
+        int bytes = 0;
+        for (int l = 1; l < 4; ++l) bytes += (m_.WH[l] * m_.WW[l] * kRowBytes + 1023) & ~1023;
+        return bytes + 4 * kMaxQueries <= kMaxLds && most_queries <= kMaxQueries;
+    };
+    if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, 16.7, 41.75, fits))
+        return DATR_EUNSUPPORTED;
+    {
+        int bytes = 0;
+        for (int l = 1; l < 4; ++l) {
+            pm.lds_base[l] = bytes;
+            // whole 1 KiB LDS-DMA pieces: the zero-filled tail lanes of a level's last piece must
+            // not land in the next level's window
+            bytes += (pm.WH[l] * pm.WW[l] * kRowBytes + 1023) & ~1023;
+        }
+        pm.lds_base[0] = 0;
+        pm.lds_bytes = bytes;
+    }
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_fwd_pyr_d32),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     kMaxLds) == hipSuccess;
