@@ -36,11 +36,38 @@
 #include "datr_hip.h"
 #include "msda_pyr.h"
 
+#ifdef PYR_PROBE
+// per-phase cycle counters of lane 0 of every wave (development builds only)
+__device__ unsigned long long pyr_bwd_phase_cycles[1024][8];
+#define TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                     ticks_[i] += now_ - tick_; tick_ = now_; } while (0)
+extern "C" void datr_probe_pyr_bwd_phase_cycles(unsigned long long *out, int reset) {
+    static unsigned long long all[1024][8];
+    (void)hipMemcpyFromSymbol(all, HIP_SYMBOL(pyr_bwd_phase_cycles), sizeof(all));
+    for (int i = 0; i < 8; ++i) {
+        out[i] = 0;
+        for (int b = 0; b < 1024; ++b) out[i] += all[b][i];
+    }
+    if (reset) {
+        static unsigned long long z[1024][8];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pyr_bwd_phase_cycles), z, sizeof(z));
+    }
+}
+#else
+#define TICK(i) do {} while (0)
+#endif
+
 namespace {
 
-constexpr int kThreads = 768;
+#ifndef PYRB_THREADS
+#define PYRB_THREADS 512
+#endif
+#ifndef PYRB_MAXQ
+#define PYRB_MAXQ 256
+#endif
+constexpr int kThreads = PYRB_THREADS;
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxQ = 512;                 // queries of a region
+constexpr int kMaxQ = PYRB_MAXQ;           // queries of a region
 constexpr int kMaxRows = 1024;             // rows of a level's window
 constexpr int kMaxTasks = (kMaxQ / 16 + kWaves - 1) / kWaves;      // 16-query tasks per wave: 3
 constexpr unsigned kOutOfRange = 0x80000000u;
@@ -54,7 +81,7 @@ constexpr int kCurOff = kHistOff + (2 * kThreads) * 4;     // cursors
 constexpr int kTabOff = kCurOff + (2 * kThreads) * 4;      // query slot -> pyramid index
 constexpr int kScanOff = kTabOff + kMaxQ * 4;              // per-wave totals of the scan
 constexpr int kLdsBytes = kScanOff + 64;
-static_assert(kMaxRows + 1 <= 2 * kThreads, "the scan gives every thread two histogram entries");
+static_assert(kMaxRows + 1 <= 2 * kThreads || true, "the scan gives every thread two histogram entries");
 static_assert(kLdsBytes <= 160 * 1024, "LDS");
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -105,6 +132,10 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
     unsigned long long *recs = reinterpret_cast<unsigned long long *>(lds + kRecOff);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PYR_PROBE
+    unsigned long long ticks_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
     const int bid = blockIdx.x;
     const int m = bid % M;
     const int reg = (bid / M) % (pm.nRy * pm.nRx);
@@ -147,6 +178,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TICK(0);                                   // set-up: query table, grad_out rows
 
     // lane roles (as in msda_fwd_pyr.hip): 4 lanes per query, lane j = point j's geometry and the
     // 16-B pieces 16 j / 16 j + 64 of every row
@@ -200,7 +232,9 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
             }
             smp[k] = s;
         }
+        TICK(1);                               // pass A: geometry + counts
         __syncthreads();
+        TICK(2);                               // barriers + scan
 
         // ---- exclusive scan of the counts (two entries per thread) ------------------------------
         {
@@ -221,6 +255,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
             if (i1 <= rows) { hist[i1] = excl + c0; cur[i1] = excl + c0; }
         }
         __syncthreads();
+        TICK(2);
 
         // ---- pass B: records, grad_attn / grad_loc ----------------------------------------------
 #pragma unroll
@@ -305,7 +340,9 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
                 reinterpret_cast<f2 *>(grad_loc)[idx] = f2{pw * s.a * Wf, ph * s.a * Hf};
             }
         }
+        TICK(3);                               // pass B: records, gathers, dots
         __syncthreads();
+        TICK(2);
 
         // ---- reduce: a window row's gradient is a gather over its records -----------------------
         {
@@ -344,8 +381,14 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
                 __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.w, gsrc, o_ + 12, 0, 0);
             }
         }
+        TICK(4);                               // reduce + flush
         __syncthreads();
+        TICK(2);
     }
+#ifdef PYR_PROBE
+    if (lane == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&pyr_bwd_phase_cycles[(blockIdx.x * kWaves + wave) & 1023][i], ticks_[i]);
+#endif
 }
 
 }  // namespace
@@ -364,10 +407,25 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
     const auto fits = [](const PyrMeta &m_, int most_queries) {
         int rows = 0;
         for (int l = 0; l < 4; ++l) rows = std::max(rows, m_.WH[l] * m_.WW[l]);
-        return rows <= kMaxRows && most_queries <= kMaxQ;
+        return rows <= kMaxRows && rows + 1 <= 2 * kThreads && most_queries <= kMaxQ;
     };
-    if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, 12.5, 28.0, fits))
+    if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, kMaxQ >= 512 ? 12.5 : 10.0,
+                        kMaxQ >= 512 ? 28.0 : 16.7, fits))
         return DATR_EUNSUPPORTED;
+    // The windows are index spaces here (nothing is staged), so the halo may be as wide as the
+    // 1024-row histogram allows: samples beyond it take the slow direct-atomic path.
+    {
+        static const float wide[3][4] = {{6.f, 8.f, 10.f, 12.f}, {5.5f, 7.f, 9.f, 11.f}, {5.f, 6.f, 7.f, 8.f}};
+        for (int i = 0; i < 3; ++i) {
+            float h4[4];
+            for (int l = 0; l < 4; ++l) h4[l] = std::max(halo, wide[i][l]);
+            PyrMeta wider;
+            if (build_pyr_meta(wider, shapes_host, level_start_host, S, h4, 10.0, 16.7, fits, pm.nRy, pm.nRx)) {
+                pm = wider;
+                break;
+            }
+        }
+    }
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     kLdsBytes) == hipSuccess;

@@ -30,9 +30,11 @@ inline long pyr_ceil_div(long a, long b) { return a >= 0 ? (a + b - 1) / b : -((
 // Regions start at about target_h x target_w level-0 pixels and shrink until fits(pm, queries of
 // the largest region) holds.  halo: how far (pixels of the sampled level) a sample may lie from
 // its query's reference point and still be inside the window.
+// `halo` may also be given per level; force_ry / force_rx > 0 try exactly that grid.
 template <typename Fits>
-inline bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, int64_t S, float halo,
-                           double target_h, double target_w, Fits fits) {
+inline bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, int64_t S,
+                           const float (&halo)[4], double target_h, double target_w, Fits fits,
+                           int force_ry = 0, int force_rx = 0) {
     long total = 0;
     for (int l = 0; l < 4; ++l) {
         const long H = sh[2 * l], W = sh[2 * l + 1];
@@ -47,7 +49,9 @@ inline bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, in
     const int H0 = pm.H[0], W0 = pm.W[0];
     int nRy = std::min(kPyrMaxR, std::max(1, (int)std::lround(H0 / target_h)));
     int nRx = std::min(kPyrMaxR, std::max(1, (int)std::lround(W0 / target_w)));
-    if (const char *e = std::getenv("DATR_MSDA_PYR_REGIONS")) {          // development: "RYxRX"
+    if (force_ry > 0 && force_rx > 0) {
+        nRy = std::min(kPyrMaxR, force_ry); nRx = std::min(kPyrMaxR, force_rx);
+    } else if (const char *e = std::getenv("DATR_MSDA_PYR_REGIONS")) {          // development: "RYxRX"
         int a = 0, b = 0;
         if (std::sscanf(e, "%dx%d", &a, &b) == 2 && a >= 1 && b >= 1 && a <= kPyrMaxR && b <= kPyrMaxR) {
             nRy = a; nRx = b;
@@ -81,7 +85,7 @@ inline bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, in
                         hi = std::max(hi, (qb[lq][i + 1] - 0.5) / dim[lq] * dim[l] - 0.5);
                     }
                     if (lo > hi) { lo = hi = 0; }
-                    const int a = (int)std::floor(lo - halo), b = (int)std::floor(hi + halo) + 1;
+                    const int a = (int)std::floor(lo - halo[l]), b = (int)std::floor(hi + halo[l]) + 1;
                     w0[l][i] = (short)a;
                     widest = std::max(widest, b - a + 1);
                 }
@@ -99,12 +103,20 @@ inline bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, in
                 most = std::max(most, c);
             }
         if (fits(pm, most)) return true;
+        if (force_ry > 0 && force_rx > 0) return false;
         // too large: more, smaller regions along the longer region side
         if ((double)H0 / nRy >= (double)W0 / nRx && nRy < kPyrMaxR) ++nRy;
         else if (nRx < kPyrMaxR) ++nRx;
         else if (nRy < kPyrMaxR) ++nRy;
         else return false;
     }
+}
+
+template <typename Fits>
+inline bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, int64_t S, float halo,
+                           double target_h, double target_w, Fits fits) {
+    const float h4[4] = {halo, halo, halo, halo};
+    return build_pyr_meta(pm, sh, ls, S, h4, target_h, target_w, fits);
 }
 
 inline float pyr_halo_from_env() {

@@ -127,6 +127,19 @@ def main():
                     f"{n}={100 * v / tot:.1f}%" for n, v in zip(
                         ["fill-issue", "fill-land", "barrier", "locwait+geom", "gathers", "slow+store", "tail-wait"], buf)),
                     f"total={tot / 1e6:.1f} Mcycles")
+            if os.environ.get("PYR_PROBE_BWD") and Lq == 22223:
+                import ctypes
+                from datr_amd import _native
+                buf = (ctypes.c_ulonglong * 8)()
+                _native.lib.datr_probe_pyr_bwd_phase_cycles(buf, 1)
+                b()
+                torch.cuda.synchronize()
+                _native.lib.datr_probe_pyr_bwd_phase_cycles(buf, 1)
+                tot = sum(buf) or 1
+                print("pyr bwd phase cycles: " + ", ".join(
+                    f"{n}={100 * v / tot:.1f}%" for n, v in zip(
+                        ["setup", "passA", "barrier+scan", "passB", "reduce+flush"], buf)),
+                    f"total={tot / 1e6:.1f} Mcycles")
             print(json.dumps({
                 "dist": dist, "Lq": Lq, "N": N, "pyr_fwd": msda.PYR_FORWARD,
                 "fwd_us_median": round(fm, 2), "fwd_us_min": round(fmin, 2),
