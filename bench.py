@@ -78,20 +78,25 @@ class MsdaTimer:
         N, S, M, D, K, Lq = self.shape
         algo_bytes = 4 * N * (S * M * D + Lq * M * K * 3 + Lq * M * D)
         mean_us = sum(us) / len(us)
-        # HBM traffic per launch from the PMC passes committed under profiles/ (same kernel,
-        # N=2 shape; FETCH_SIZE corrected as the micro-architecture guide prescribes); scales
-        # linearly with N for the merged source+target encoder call
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc.json")
+        # HBM traffic per launch from the PMC passes committed under profiles/ (same kernel, same
+        # N = 4 launch; FETCH_SIZE corrected as the micro-architecture guide prescribes).  PMC
+        # counters cannot be collected inside this process: null when the shape differs.
+        traffic, kernel = None, "msda forward (encoder call)"
+        pmc = os.path.join(ROOT, "profiles", "r02_msda_pmc.json")
         if os.path.exists(pmc):
             rec = json.load(open(pmc))
             sh = rec["shape"]
-            if (sh["S"], sh["M"], sh["D"], sh["Lq"]) == (S, M, D, Lq) and sh["L"] * sh["P"] == K:
-                traffic = int(rec["traffic_bytes"] * N / sh["N"])
+            if (sh["N"], sh["S"], sh["M"], sh["D"], sh["Lq"]) == (N, S, M, D, Lq) and sh["L"] * sh["P"] == K \
+                    and self.msda.PYR_FORWARD:
+                traffic = int(rec["traffic_bytes"])
+        if self.msda.PYR_FORWARD and D == 32 and K == 16:
+            kernel = "msda_fwd_pyr_d32 (encoder call, csrc/msda_fwd_pyr.hip)"
+        else:
+            kernel = "msda_fwd_rows<8,16> (encoder call)"
         achieved = algo_bytes / mean_us / 1e3
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "kernel": "msda_fwd_rows<8,16> (encoder call)", "launches": len(us),
+                "kernel": kernel, "launches": len(us),
                 "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
 
 
