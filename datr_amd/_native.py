@@ -42,6 +42,8 @@ _SIGNATURES = {
     "datr_msda_prologue_forward_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_msda_prologue_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "datr_mha_forward_d32_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_float, _vp, _vp, _vp],
+    "datr_mha_backward_d32_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_float,
+                                  _vp, _vp, _vp, _vp, _vp],
     "datr_match_cost_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
                             ctypes.c_float, ctypes.c_float, _vp, _vp, _vp],
     "datr_box_loss_forward_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp],

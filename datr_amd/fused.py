@@ -348,23 +348,10 @@ def conv3x3_lrelu_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
 
 
 # ---------------------------------------------------------------------------------------------
-# Scaled-dot-product attention, head_dim 32: own MFMA forward (csrc/mha_fwd.hip), PyTorch's
-# memory-efficient backward fed with the own (out, log-sum-exp).
+# Scaled-dot-product attention, head_dim 32: own exact-fp32 MFMA forward (csrc/mha_fwd.hip) and
+# backward (csrc/mha_bwd.hip: query-stationary dQ + key-stationary dK/dV, fed with the forward's
+# output and log-sum-exp).
 # ---------------------------------------------------------------------------------------------
-_PHILOX = {}
-
-
-def _philox_placeholders(device):
-    """The (seed, offset) tensors PyTorch's efficient-attention backward wants; unused at
-    dropout 0 -- taken once from a tiny forward call so that dtype / device are whatever this
-    build expects."""
-    if device not in _PHILOX:
-        z = torch.zeros(1, 1, 32, 32, device=device)
-        res = torch.ops.aten._scaled_dot_product_efficient_attention(z, z, z, None, True, 0.0, False)
-        _PHILOX[device] = (res[2], res[3])
-    return _PHILOX[device]
-
-
 class _AttentionD32(Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, heads):
@@ -389,14 +376,25 @@ class _AttentionD32(Function):
         q, k, v, out, lse, mask = ctx.saved_tensors
         L, N, E = q.shape
         H = ctx.heads
-        to4 = lambda x: x.reshape(L, N, H, 32).permute(1, 2, 0, 3)           # [N, H, L, 32] views
-        bias = None if mask is None else mask.view(1, 1, L, L).expand(N, H, L, L)
-        seed, offset = _philox_placeholders(q.device)
-        dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
-            to4(dout.contiguous()), to4(q), to4(k), to4(v), bias, to4(out), lse, seed, offset, 0.0,
-            [True, True, True, False], False)
-        back = lambda g: g.permute(2, 0, 1, 3).reshape(L, N, E)
-        return back(dq), back(dk), back(dv), None, None
+        if dout.stride(-1) != 1 or dout.stride(0) % 4 or dout.stride(1) % 4:
+            dout = dout.contiguous()
+        # one buffer for the three gradients: q and k are column slices of ONE merged projection in
+        # the decoder (transformer._self_attention), so their gradients land side by side
+        grads = torch.empty(L, N, 3 * E, device=q.device, dtype=torch.float32)
+        dq, dk, dv = grads[..., :E], grads[..., E:2 * E], grads[..., 2 * E:]
+        delta = torch.empty(N, H, L, device=q.device, dtype=torch.float32)
+        strides = (ctypes.c_int64 * 16)(q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                        v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+                                        dout.stride(0), dout.stride(1), dq.stride(0), dq.stride(1),
+                                        dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1))
+        with torch.cuda.device(q.device):
+            rc = _native.lib.datr_mha_backward_d32_f32(
+                dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                0 if mask is None else mask.data_ptr(), L, N, H, ctypes.addressof(strides), 32 ** -0.5,
+                delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                _native.current_stream_ptr(q.device))
+        _native.check(rc, "mha_backward_d32")
+        return dq, dk, dv, None, None
 
 
 def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask, heads: int) -> torch.Tensor:

@@ -73,7 +73,8 @@ def _self_attention(mha: nn.MultiheadAttention, qk_in: Tensor, v_in: Tensor, att
     fewer launches: the query and key projections share their input, so they are ONE GEMM
     (nn.MultiheadAttention runs three because value differs); linears go through fused.linear
     (column-sum bias gradients); the in_proj parameters are split, not sliced (one backward
-    node).  Scaled dot-product attention itself is PyTorch's kernel."""
+    node).  Scaled dot-product attention itself is the own MFMA kernel pair (csrc/mha_fwd.hip,
+    csrc/mha_bwd.hip) for head_dim 32 in fp32, PyTorch's otherwise."""
     L, N, E = qk_in.shape
     H = mha.num_heads
     hd = E // H
@@ -86,7 +87,8 @@ def _self_attention(mha: nn.MultiheadAttention, qk_in: Tensor, v_in: Tensor, att
             .masked_fill_(attn_mask, float("-inf"))
     if OWN_ATTENTION and hd == 32 and q.dtype == torch.float32 and all(
             x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0 for x in (q, k, v)):
-        # own MFMA forward (csrc/mha_fwd.hip), output already in the [L, N, E] layout out_proj reads
+        # own MFMA forward / backward (csrc/mha_fwd.hip, mha_bwd.hip), output already in the [L, N, E]
+        # layout out_proj reads
         out = attention_d32(q, k, v, None if attn_mask is None else attn_mask.contiguous(), H)
         out = out.view(L * N, E)
     else:

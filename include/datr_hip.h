@@ -220,6 +220,18 @@ int datr_mha_forward_d32_f32(const float *q, const float *k, const float *v, con
                              int64_t L, int64_t N, int64_t H, const int64_t *strides, float scale,
                              float *out, float *lse, void *stream);
 
+/* Backward of the same attention, fed with the forward's `out` and `lse`: grad_q = scale dS K,
+ * grad_k = scale dS^T Q, grad_v = P^T dO with P = exp(scale Q K^T + mask - lse),
+ * dS = P o (dO V^T - D), D = rowsum(dO o out)  (autograd of nn.MultiheadAttention's softmax
+ * attention, deformable_transformer.py:880-884).  Two launches (query-stationary dQ, key-stationary
+ * dK/dV), no atomics: bitwise reproducible.  strides = {q_l, q_n, k_l, k_n, v_l, v_n, o_l, o_n,
+ * go_l, go_n, dq_l, dq_n, dk_l, dk_n, dv_l, dv_n} in floats, multiples of 4; delta = [N, H, L]
+ * scratch (receives D); the three gradients are fully overwritten. */
+int datr_mha_backward_d32_f32(const float *grad_out, const float *q, const float *k, const float *v,
+                              const float *out, const float *lse, const float *mask, int64_t L,
+                              int64_t N, int64_t H, const int64_t *strides, float scale, float *delta,
+                              float *grad_q, float *grad_k, float *grad_v, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Cost matrix of the Hungarian matcher (/root/reference/models/dino/matcher.py:48-88) for `sets`
  * = (prediction sets x images) blocks of nq queries against all T ground-truth boxes of the

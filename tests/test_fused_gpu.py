@@ -312,6 +312,46 @@ def test_decoder_self_attention_matches_nn_multihead_attention(L):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("L,masked", [(64, False), (300, True), (301, True), (1100, True), (1100, False)])
+def test_attention_d32_forward_and_backward_match_float64_math(L, masked):
+    """csrc/mha_fwd.hip + csrc/mha_bwd.hip against softmax(q k^T / sqrt(32) + mask) v written out in
+    float64 under autograd: q and k are column slices of one merged buffer (the decoder's layout),
+    the gradient arrives non-contiguous; two backward runs are bitwise identical (no atomics)."""
+    from datr_amd.fused import attention_d32
+    dev = torch.device("cuda:0")
+    torch.manual_seed(L)
+    N, H = 3, 8
+    E = 32 * H
+    qk = torch.randn(L, N, 2 * E, device=dev).requires_grad_(True)
+    v = torch.randn(L, N, E, device=dev).requires_grad_(True)
+    mask = None
+    if masked:
+        mask = torch.zeros(L, L, device=dev)
+        mask[100:, :100] = float("-inf")
+        mask[:50, 50:100] = float("-inf")
+        mask[50:100, :50] = float("-inf")
+        mask += 0.1 * torch.randn(L, L, device=dev)            # a finite additive part as well
+    go = torch.randn(N, L, E, device=dev).transpose(0, 1)      # non-contiguous incoming gradient
+    q, k = qk.split(E, dim=-1)
+    out = attention_d32(q, k, v, mask, H)
+    g_qk, g_v = torch.autograd.grad(out, (qk, v), go, retain_graph=True)
+    g_qk2, g_v2 = torch.autograd.grad(out, (qk, v), go)
+    assert torch.equal(g_qk, g_qk2) and torch.equal(g_v, g_v2)
+
+    qd = qk.detach().double().requires_grad_(True)
+    vd = v.detach().double().requires_grad_(True)
+    q4, k4 = (x.reshape(L, N, H, 32).permute(1, 2, 0, 3) for x in qd.split(E, dim=-1))
+    v4 = vd.reshape(L, N, H, 32).permute(1, 2, 0, 3)
+    s = q4 @ k4.transpose(-1, -2) / 32 ** 0.5
+    if mask is not None:
+        s = s + mask.double()
+    ref = (s.softmax(-1) @ v4).permute(2, 0, 1, 3).reshape(L, N, E)
+    r_qk, r_v = torch.autograd.grad(ref, (qd, vd), go.double())
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(g_qk.double(), r_qk, rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(g_v.double(), r_v, rtol=1e-5, atol=5e-6)
+
+
 @pytest.mark.parametrize("ref_dim,Lq", [(2, 701), (4, 300)])
 def test_fused_sampling_prologue_matches_torch_ops(ref_dim, Lq):
     """csrc/msda_prologue.hip (softmax + sampling locations from the merged query projection,
