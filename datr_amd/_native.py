@@ -50,15 +50,24 @@ _SIGNATURES = {
     "datr_box_loss_backward_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "datr_sine_embed_f32": [_vp, _vp, _i64, _i64, _vp, _vp],
     "datr_topk_rows_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "datr_nms_f32": [_vp, _vp, _vp, _i64, ctypes.c_float, _vp, _vp, _vp],
     "datr_gemm_k256_f32": [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp],
     "datr_conv3x3_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
                                       ctypes.c_float, _vp, _vp],
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "datr_wino_weights_f32": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
+    "datr_conv3x3_wino_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, _vp],
     "datr_focal_loss_forward_f32": [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
                                     _vp, _vp, _vp],
     "datr_focal_loss_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float,
                                      ctypes.c_float, _vp, _vp],
 }
+
+
+class WinoLevel(ctypes.Structure):
+    """`datr_wino_level` of include/datr_hip.h."""
+    _fields_ = [("x", _vp), ("y", _vp), ("gate", _vp), ("H", _i64), ("W", _i64)]
 
 
 class NativeLibraryError(RuntimeError):

@@ -1,0 +1,337 @@
+// wino.hip -- Winograd F(2x2, 3x3) convolution on the MFMA units, exact fp32, NHWC: the 3x3 /
+// stride 1 / pad 1 convolutions of DATR's image-level domain discriminator (`FCDiscriminator_img`,
+// /root/reference/models/dino/DA_utils.py:61-79, applied to the four pyramid levels of all 2B
+// images behind the gradient-reversal layer, /root/reference/models/dino/dino.py:351-359) -- the
+// forward with bias + LeakyReLU fused, and the data gradient (the same kernel on dY with the
+// transposed / flipped filter) with the LeakyReLU gate of the previous layer and the GRL sign fused.
+//
+//   Y = A^T [ sum_ci (G g G^T) o (B^T d B) ] A        (Lavin & Gray's minimal filtering, 2.25x fewer
+//   multiplies than the direct form; MIOpen's fp32 kernel for these layers is the same algorithm on
+//   the VALU, this one runs the 16 per-position channel contractions as v_mfma_f32_32x32x2_f32).
+//
+// Work split: a workgroup = 8 x 8 tiles (16 x 16 output pixels) x 64 output channels; wave (a, b)
+// owns tiles 32 a .. 32 a + 31 and channels 32 b .. 32 b + 31 for ALL 16 transform positions: 16
+// accumulator blocks = 256 AGPRs, so the inverse transform A^T M A is lane-local (no exchange) and a
+// lane's 32-lane row stores 128 contiguous bytes of NHWC output.  Input channels go by in chunks of
+// 8, software-pipelined with ONE barrier per chunk: while chunk c is multiplied, the raw 18 x 18
+// patch of chunk c + 1 (staged in LDS, zero outside the image) is turned into V = B^T d B -- each
+// thread owns (tile, 4 channels, 2 of the 4 transform rows), a sixteenth of that work is issued
+// between the MFMAs of each position -- the transformed filter slab of chunk c + 1 (32 KB,
+// [pos][k-half][cout][4] so that every ds_read_b128 group is bank-conflict free) arrives by LDS-DMA,
+// the raw patch of chunk c + 2 is written to LDS and that of chunk c + 3 is in flight in registers.
+// All levels of the pyramid share the filter, so they are ONE launch (level table in the arguments).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "datr_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int TB = 8;                          // tiles per workgroup edge
+constexpr int PW = 2 * TB + 2;                 // patch edge (18)
+constexpr int PPIX = PW * PW;                  // 324
+constexpr int CK = 8;                          // input channels per chunk
+constexpr int BN = 64;                         // output channels per workgroup
+constexpr int kPatchF = 2 * PPIX * 4;          // floats: [half][pixel][4]
+constexpr int kVF = 16 * 2 * 64 * 4;           // floats: [pos][half][tile][4]
+constexpr int kBF = 16 * 2 * BN * 4;           // floats per filter slab: [pos][half][cout][4]
+constexpr int kLdsBytes = (2 * kPatchF + 2 * kVF + 2 * kBF) * 4;   // 148.7 KB: everything double-buffered
+
+struct WinoLevel { const float *x; float *y; const float *gate; int H, W, tbx, tby, first; };
+struct WinoArgs { WinoLevel lv[DATR_WINO_MAX_LEVELS]; int nlevels, Cin, Cout; float slope, gate_slope, out_scale; };
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+__global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const float *__restrict__ U,
+                                                           const float *__restrict__ scale,
+                                                           const float *__restrict__ shift)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                       // [2 buffers][2][324][4]
+    float *Vs = patch + 2 * kPatchF;           // [2 buffers][16][2][64][4]
+    float *Bs = Vs + 2 * kVF;                  // [2 buffers][16][2][64][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wa = wave >> 1, wb = wave & 1;
+
+    // ---- which level / image / tile block ------------------------------------------------------
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < DATR_WINO_MAX_LEVELS; ++i)
+        if (i < args.nlevels && (int)blockIdx.x >= args.lv[i].first) lvl = i;
+    const WinoLevel L = args.lv[lvl];
+    int r = blockIdx.x - L.first;
+    const int tbx = r % L.tbx; r /= L.tbx;
+    const int tby = r % L.tby;
+    const int n = r / L.tby;
+    const int H = L.H, W = L.W, Cin = args.Cin, Cout = args.Cout;
+    const int y0 = tby * 2 * TB, x0 = tbx * 2 * TB;
+    const int co0 = blockIdx.y * BN;
+    const float *Xn = L.x + (size_t)n * H * W * Cin;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+
+    // filter slab of chunk c -> Bs[buf]: per (pos, half) 64 couts x 16 B = 1 KiB contiguous in
+    // U[pos][Cin/8][2][Cout][4]; 32 pieces, 8 per wave, one LDS-DMA instruction each
+    const int nchunks = Cin / CK;
+    // (inline asm, not the builtin: the compiler would make every later ds_read wait for the DMA --
+    // vmcnt(0) right after issue -- and serialise the copy with the multiplication it should hide
+    // behind; completion is awaited explicitly before the chunk's closing barrier)
+    const unsigned bs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float *)Bs;
+    auto dma_b = [&](int c, int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int piece = wave * 8 + u;                    // = pos * 2 + half
+            const int pos = piece >> 1, half = piece & 1;
+            const float *src = U + ((((size_t)pos * nchunks + c) * 2 + half) * Cout + co0 + lane) * 4;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(bs_lds + (buf * kBF + piece * BN * 4) * 4);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory");
+        }
+    };
+    // raw patch of chunk c: 324 pixels x 2 float4, zero outside the image; register-staged so that
+    // the loads of chunk c + 1 are in flight while chunk c is multiplied
+    float4 pf[3];
+    auto fetch_patch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int f = tid + u * kThreads;
+            const int pix = f >> 1, h = f & 1;
+            const int py = pix / PW, px = pix - py * PW;
+            const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < 2 * PPIX && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v = *reinterpret_cast<const float4 *>(Xn + ((size_t)yy * W + xx) * Cin + c * CK + h * 4);
+            pf[u] = v;
+        }
+    };
+    auto store_patch = [&](float *dst) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int f = tid + u * kThreads;
+            const int pix = f >> 1, h = f & 1;
+            if (f < 2 * PPIX) *reinterpret_cast<float4 *>(&dst[(h * PPIX + pix) * 4]) = pf[u];
+        }
+    };
+
+    // transform unit of this thread: (tile, channel half, pair of transform rows); the pair is
+    // wave-uniform (waves 0,1: rows 0,1 from patch rows 0-2; waves 2,3: rows 2,3 from patch rows 1-3)
+    const int t_tile = tid & 63, t_half = (tid >> 6) & 1;
+    const int t_pair = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    const int p_off = (t_half * PPIX + (2 * t_ty + t_pair) * PW + 2 * t_tx) * 4;
+    const int v_off = (((t_pair * 2 * 4) * 2 + t_half) * 64 + t_tile) * 4;          // xi = 2 pair, nu = 0
+    constexpr int kVPos = 2 * 64 * 4;          // floats between consecutive positions of V / a filter slab
+
+    float4 d[3][4], tq[4];
+    auto tr_load = [&](const float *pb, int k) {               // two of the 12 raw patch float4
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rr = (2 * k + u) >> 2, cc = (2 * k + u) & 3;
+            d[rr][cc] = *reinterpret_cast<const float4 *>(pb + p_off + (rr * PW + cc) * 4);
+        }
+    };
+    auto tr_rows = [&](int q) {                                // t = (B^T d) row xi = 2 pair + q
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            if (t_pair == 0) tq[cc] = q == 0 ? f4sub(d[0][cc], d[2][cc]) : f4add(d[1][cc], d[2][cc]);
+            else             tq[cc] = q == 0 ? f4sub(d[1][cc], d[0][cc]) : f4sub(d[0][cc], d[2][cc]);
+        }
+    };
+    auto tr_store = [&](float *vbuf, int q, int hi) {          // V[xi][2 hi], V[xi][2 hi + 1] = (t B)
+        float *vb = vbuf + v_off + q * 4 * kVPos + hi * 2 * kVPos;
+        if (hi == 0) {
+            *reinterpret_cast<float4 *>(vb) = f4sub(tq[0], tq[2]);
+            *reinterpret_cast<float4 *>(vb + kVPos) = f4add(tq[1], tq[2]);
+        } else {
+            *reinterpret_cast<float4 *>(vb) = f4sub(tq[2], tq[1]);
+            *reinterpret_cast<float4 *>(vb + kVPos) = f4sub(tq[1], tq[3]);
+        }
+    };
+    // slot k of 16: a 16th of the transform of one chunk (12 loads, 2 x (rows, 2 stores))
+    auto tr_piece = [&](const float *pb, float *vbuf, int k) {
+        if (k < 6) tr_load(pb, k);
+        else if (k == 6) tr_rows(0);
+        else if (k == 7) tr_store(vbuf, 0, 0);
+        else if (k == 8) tr_store(vbuf, 0, 1);
+        else if (k == 9) tr_rows(1);
+        else if (k == 10) tr_store(vbuf, 1, 0);
+        else if (k == 11) tr_store(vbuf, 1, 1);
+    };
+
+    // ---- prologue: patches 0, 1 in LDS, patch 2 in registers, slab 0 on its way, V(0) computed ------
+    fetch_patch(0);
+    dma_b(0, 0);
+    store_patch(patch);
+    if (nchunks > 1) { fetch_patch(1); store_patch(patch + kPatchF); }
+    if (nchunks > 2) fetch_patch(2);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 12; ++k) tr_piece(patch, Vs, k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int a_off = (lhi * 64 + wa * 32 + l31) * 4;
+    const int b_off = (lhi * BN + wb * 32 + l31) * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        // invariant: V[buf], Bs[buf] hold chunk c; patch[buf ^ 1] holds the raw chunk c + 1; the
+        // registers hold the raw chunk c + 2; every wave is past its reads of chunk c - 1
+        if (c + 2 < nchunks) store_patch(patch + buf * kPatchF);
+        if (c + 3 < nchunks) fetch_patch(c + 3);
+        const bool more = c + 1 < nchunks;
+        if (more) dma_b(c + 1, buf ^ 1);
+
+        // 16 positions x (32 tiles x 32 couts) += V[pos] U[pos] over the 8 channels of chunk c, with the
+        // transform of chunk c + 1 issued in the shadow of the MFMAs (one sixteenth per position)
+        const float *va = Vs + buf * kVF + a_off;
+        const float *vbs = Bs + buf * kBF + b_off;
+        const float *pnext = patch + (buf ^ 1) * kPatchF;
+        float *vnext = Vs + (buf ^ 1) * kVF;
+        float4 a4 = *reinterpret_cast<const float4 *>(va);
+        float4 b4 = *reinterpret_cast<const float4 *>(vbs);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            float4 an = a4, bn = b4;
+            if (p < 15) {
+                an = *reinterpret_cast<const float4 *>(va + (p + 1) * kVPos);
+                bn = *reinterpret_cast<const float4 *>(vbs + (p + 1) * kVPos);
+            }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[p], 0, 0, 0);
+            if (more) tr_piece(pnext, vnext, p);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a4 = an; b4 = bn;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab c + 1 (this wave's pieces) landed
+        __syncthreads();
+    }
+
+    // ---- inverse transform + epilogue, lane-local: lane = cout, register e = tile ------------------
+    const int co = co0 + wb * 32 + l31;
+    const float sc = scale ? scale[co] : 1.f;
+    const float sh = shift ? shift[co] : 0.f;
+    const float slope = args.slope, gslope = args.gate_slope, oscale = args.out_scale;
+    float *Yn = L.y + (size_t)n * H * W * Cout;
+    const float *Gn = L.gate ? L.gate + (size_t)n * H * W * Cout : nullptr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int tile = wa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
+        float tmp[4][2];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float m0 = acc[xi * 4][e], m1 = acc[xi * 4 + 1][e], m2 = acc[xi * 4 + 2][e], m3 = acc[xi * 4 + 3][e];
+            tmp[xi][0] = m0 + m1 + m2;
+            tmp[xi][1] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float yv[2] = {tmp[0][j] + tmp[1][j] + tmp[2][j], tmp[1][j] - tmp[2][j] - tmp[3][j]};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = oy + i, xx = ox + j;
+                if (yy < H && xx < W) {
+                    const size_t o = ((size_t)yy * W + xx) * Cout + co;
+                    float v = yv[i] * sc + sh;
+                    v = v > 0.f ? v : v * slope;
+                    if (Gn) v = Gn[o] > 0.f ? v : v * gslope;
+                    Yn[o] = v * oscale;
+                }
+            }
+        }
+    }
+}
+
+// U[pos][Cin/8][2][Cout][4] = G g G^T of every (ci, co) filter; flip = the data-gradient filter
+// (taps mirrored; the caller swaps the channel strides)
+__global__ void wino_weights(const float *__restrict__ w, long s_co, long s_ci, long s_r, long s_s, int flip,
+                             int Cin, int Cout, float *__restrict__ U)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cin * Cout) return;
+    const int co = idx % Cout, ci = idx / Cout;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int rr = flip ? 2 - r : r, qq = flip ? 2 - q : q;
+            g[r][q] = w[co * s_co + ci * s_ci + rr * s_r + qq * s_s];
+        }
+    float gg[4][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        gg[0][q] = g[0][q];
+        gg[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+        gg[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+        gg[3][q] = g[2][q];
+    }
+    const int nchunks = Cin / CK;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        const float u[4] = {gg[xi][0], 0.5f * (gg[xi][0] + gg[xi][1] + gg[xi][2]),
+                            0.5f * (gg[xi][0] - gg[xi][1] + gg[xi][2]), gg[xi][2]};
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            const int pos = xi * 4 + nu;
+            U[((((size_t)pos * nchunks + ci / CK) * 2 + (ci % CK) / 4) * Cout + co) * 4 + (ci & 3)] = u[nu];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int datr_wino_weights_f32(const float *w, int64_t Cout, int64_t Cin, int64_t s_co, int64_t s_ci,
+                                     int64_t s_r, int64_t s_s, int flip, float *u, void *stream) {
+    if (!w || !u || Cin <= 0 || Cout <= 0) return DATR_EINVAL;
+    if (Cin % CK != 0 || Cout % BN != 0 || Cin * Cout > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    const int total = (int)(Cin * Cout);
+    hipLaunchKernelGGL(wino_weights, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (long)s_co,
+                       (long)s_ci, (long)s_r, (long)s_s, flip, (int)Cin, (int)Cout, u);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+extern "C" int datr_conv3x3_wino_nhwc_f32(const datr_wino_level *levels, int64_t nlevels, int64_t N, int64_t Cin,
+                                          int64_t Cout, const float *u, const float *scale, const float *shift,
+                                          float slope, float gate_slope, float out_scale, void *stream) {
+    if (!levels || !u || nlevels <= 0 || N <= 0 || Cin <= 0 || Cout <= 0) return DATR_EINVAL;
+    if (nlevels > DATR_WINO_MAX_LEVELS || Cin % CK != 0 || Cout % BN != 0) return DATR_EUNSUPPORTED;
+    WinoArgs a;
+    a.nlevels = (int)nlevels; a.Cin = (int)Cin; a.Cout = (int)Cout;
+    a.slope = slope; a.gate_slope = gate_slope; a.out_scale = out_scale;
+    long blocks = 0;
+    for (int i = 0; i < DATR_WINO_MAX_LEVELS; ++i) {
+        const datr_wino_level &s = levels[i < nlevels ? i : 0];
+        if (i < nlevels) {
+            if (!s.x || !s.y || s.H <= 0 || s.W <= 0) return DATR_EINVAL;
+            if (N * s.H * s.W * (Cin > Cout ? Cin : Cout) > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+        }
+        WinoLevel &d = a.lv[i];
+        d.x = s.x; d.y = s.y; d.gate = s.gate; d.H = (int)s.H; d.W = (int)s.W;
+        d.tbx = (int)((s.W + 2 * TB - 1) / (2 * TB)); d.tby = (int)((s.H + 2 * TB - 1) / (2 * TB));
+        d.first = (int)blocks;
+        if (i < nlevels) blocks += (long)N * d.tbx * d.tby;
+    }
+    if (blocks > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    static int lds_set = 0;                    // idempotent; a race only repeats the call
+    if (!lds_set) {
+        if (hipFuncSetAttribute((const void *)wino_conv_nhwc, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLdsBytes) != hipSuccess) return DATR_ELAUNCH;
+        lds_set = 1;
+    }
+    dim3 grid((unsigned)blocks, (unsigned)(Cout / BN));
+    hipLaunchKernelGGL(wino_conv_nhwc, grid, dim3(kThreads), kLdsBytes, (hipStream_t)stream, a, u, scale, shift);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}

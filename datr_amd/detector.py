@@ -294,7 +294,7 @@ class DINO(nn.Module):
                 with torch.cuda.stream(side):
                     for src in srcs_all:
                         src.record_stream(side)
-                    d_out = [self.D_img(grad_reverse(src)) for src in srcs_all]
+                    d_out = self.D_img.reversed_pyramid(srcs_all)
                     backbone_da = torch.cat([o.flatten(2).transpose(1, 2) for o in d_out], dim=1)
                     backbone_da.record_stream(main)
                     done = torch.cuda.Event()
@@ -303,7 +303,7 @@ class DINO(nn.Module):
                 backbone_da._ready_event = done
                 da_output["backbone_DA"] = backbone_da
             else:
-                d_out = [self.D_img(grad_reverse(src)) for src in srcs_all]
+                d_out = self.D_img.reversed_pyramid(srcs_all)
                 da_output["backbone_DA"] = torch.cat([o.flatten(2).transpose(1, 2) for o in d_out], dim=1)
 
             # 2. class-wise query prototypes, source domain

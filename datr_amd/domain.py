@@ -9,8 +9,17 @@ so values agree to fp32 rounding, the argmax class map and counts are exact.
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
+import torch.nn.functional as F
 from torch import nn
+from torch.autograd.function import once_differentiable
+
+# own Winograd-on-MFMA path for the discriminator's 3x3 convolutions (csrc/wino.hip); 0 = the
+# library convolutions under autograd (A/B measurements)
+OWN_D_IMG = os.environ.get("DATR_OWN_D_IMG", "1") != "0"
 
 
 def decompose_features(srcs, masks, poss):
@@ -35,6 +44,116 @@ def grad_reverse(x):
     return GradReverse.apply(x)
 
 
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def wino_filter(w: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
+    """Winograd-domain filter G g G^T of a [Cout, Cin, 3, 3] weight in the layout csrc/wino.hip reads
+    ([16][Cin/8][2][Cout][4]); data_gradient=True gives the filter of the transposed convolution
+    (channels swapped, taps mirrored)."""
+    from . import _native
+    co, ci = w.shape[:2]
+    s = w.stride()
+    if data_gradient:
+        co, ci, s = ci, co, (s[1], s[0], s[2], s[3])
+    u = torch.empty(16 * ci * co, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        rc = _native.lib.datr_wino_weights_f32(w.data_ptr(), co, ci, s[0], s[1], s[2], s[3],
+                                               1 if data_gradient else 0, u.data_ptr(),
+                                               _native.current_stream_ptr(w.device))
+    _native.check(rc, "wino_weights")
+    return u
+
+
+def wino_conv3x3(xs, u: torch.Tensor, cout: int, shift=None, scale=None, slope: float = 1.0, gates=None,
+                 gate_slope: float = 1.0, out_scale: float = 1.0):
+    """3x3 / stride 1 / pad 1 convolution of every level in `xs` (channels_last [N, Cin, H, W] device
+    tensors sharing the filter `u` from wino_filter) in ONE launch of csrc/wino.hip:
+    out = out_scale * gate(lrelu_slope(scale * conv + shift)); returns channels_last tensors."""
+    from . import _native
+    assert 1 <= len(xs) <= 4
+    N, cin = xs[0].shape[:2]
+    ys = [torch.empty((N, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32,
+                      memory_format=torch.channels_last) for x in xs]
+    levels = (_native.WinoLevel * len(xs))()
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[:2] == (N, cin)
+        assert x.is_contiguous(memory_format=torch.channels_last)
+        g = None if gates is None else gates[i]
+        if g is not None:
+            assert g.shape == y.shape and g.is_contiguous(memory_format=torch.channels_last)
+        levels[i] = _native.WinoLevel(x.data_ptr(), y.data_ptr(), 0 if g is None else g.data_ptr(),
+                                      x.shape[2], x.shape[3])
+    with torch.cuda.device(xs[0].device):
+        rc = _native.lib.datr_conv3x3_wino_nhwc_f32(
+            ctypes.addressof(levels), len(xs), N, cin, cout, u.data_ptr(),
+            0 if scale is None else scale.data_ptr(), 0 if shift is None else shift.data_ptr(),
+            slope, gate_slope, out_scale, _native.current_stream_ptr(xs[0].device))
+    _native.check(rc, "conv3x3_wino_nhwc")
+    return ys
+
+
+class _DImgPyramid(torch.autograd.Function):
+    """Gradient reversal + FCDiscriminator_img on all pyramid levels (DA_utils.py:33-79 as called
+    from dino.py:351-359).  Forward: three Winograd/MFMA launches (bias + LeakyReLU in the epilogue,
+    all levels per launch) and the 128 -> 1 classifier.  Backward: per layer the data gradient is the
+    same kernel on the transposed filter with the previous layer's LeakyReLU gate -- and, for the first
+    layer, the reversal's minus sign -- in its epilogue; weight / bias gradients come from the
+    library's weight-gradient convolution (torch.ops.aten.convolution_backward)."""
+
+    SLOPE = 0.2
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, b2, w3, b3, wc, bc, *xs):
+        xs = [_nhwc(x) for x in xs]
+        a1 = wino_conv3x3(xs, wino_filter(w1), w1.shape[0], shift=b1, slope=_DImgPyramid.SLOPE)
+        a2 = wino_conv3x3(a1, wino_filter(w2), w2.shape[0], shift=b2, slope=_DImgPyramid.SLOPE)
+        a3 = wino_conv3x3(a2, wino_filter(w3), w3.shape[0], shift=b3, slope=_DImgPyramid.SLOPE)
+        outs = [F.conv2d(a, wc, bc, padding=1) for a in a3]
+        ctx.save_for_backward(w1, w2, w3, wc, *xs, *a1, *a2, *a3)
+        ctx.levels = len(xs)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *douts):
+        n = ctx.levels
+        w1, w2, w3, wc = ctx.saved_tensors[:4]
+        rest = ctx.saved_tensors[4:]
+        xs, a1, a2, a3 = (rest[i * n:(i + 1) * n] for i in range(4))
+        slope = _DImgPyramid.SLOPE
+        conv_bwd = torch.ops.aten.convolution_backward
+
+        def wgrad(dzs, ins, w):
+            """sum over levels of (dW, db) -- the library's weight-gradient convolution"""
+            dw = db = None
+            for dz, a in zip(dzs, ins):
+                _, gw, gb = conv_bwd(dz, a, w, [w.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                     [False, True, True])
+                dw = gw if dw is None else dw.add_(gw)
+                db = gb if db is None else db.add_(gb)
+            return dw, db
+
+        # classifier (128 -> 1): library kernels; its data gradient is gated by hand
+        dz3, dwc, dbc = [], None, None
+        for do, a in zip(douts, a3):
+            da, gw, gb = conv_bwd(do.contiguous(), a, wc, [1], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                  [True, True, True])
+            dz3.append(_nhwc(torch.where(a > 0, da, da * slope)))
+            dwc = gw if dwc is None else dwc.add_(gw)
+            dbc = gb if dbc is None else dbc.add_(gb)
+        dw3, db3 = wgrad(dz3, a2, w3)
+        dz2 = wino_conv3x3(dz3, wino_filter(w3, True), w3.shape[1], gates=a2, gate_slope=slope)
+        dw2, db2 = wgrad(dz2, a1, w2)
+        dz1 = wino_conv3x3(dz2, wino_filter(w2, True), w2.shape[1], gates=a1, gate_slope=slope)
+        dw1, db1 = wgrad(dz1, xs, w1)
+        dxs = [None] * n
+        if any(ctx.needs_input_grad[8:]):
+            dxs = wino_conv3x3(dz1, wino_filter(w1, True), w1.shape[1], out_scale=-1.0)   # GRL
+        return (dw1, db1, dw2, db2, dw3, db3, dwc, dbc, *dxs)
+
+
 class FCDiscriminator_img(nn.Module):
     """3x3 convs 256->256->128->128->1 with LeakyReLU(0.2) between (per-pixel domain logit)."""
 
@@ -51,6 +170,20 @@ class FCDiscriminator_img(nn.Module):
         x = self.leaky_relu(self.conv2(x))
         x = self.leaky_relu(self.conv3(x))
         return self.classifier(x)
+
+    def reversed_pyramid(self, srcs):
+        """[self(grad_reverse(s)) for s in srcs] -- the call of dino.py:351-359.  Device float32
+        levels go through the fused Winograd/MFMA path (_DImgPyramid, all levels per launch)."""
+        srcs = list(srcs)
+        convs = (self.conv1, self.conv2, self.conv3)
+        own = (OWN_D_IMG and 1 <= len(srcs) <= 4 and all(s.is_cuda and s.dtype == torch.float32 for s in srcs)
+               and all(c.in_channels % 8 == 0 and c.out_channels % 64 == 0 for c in convs)
+               and not torch.is_autocast_enabled())
+        if not own:
+            return [self(grad_reverse(s)) for s in srcs]
+        return list(_DImgPyramid.apply(self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                       self.conv3.weight, self.conv3.bias, self.classifier.weight,
+                                       self.classifier.bias, *srcs))
 
 
 def get_prototype_class_wise(object_query_last_layer, outputs_class, num_classes,

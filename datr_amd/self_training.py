@@ -48,12 +48,13 @@ def deal_pesudo_label(unlabel_target_list, idx_list, pesudo_labels_dict, pesudo_
     return out
 
 
-def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
-    """Greedy NMS on xyxy boxes -> kept indices sorted by decreasing score (IoU without the
-    reference box_ops' +1e-6: this restates torchvision.ops.nms, which the reference calls)."""
+def nms_host(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Greedy NMS on xyxy boxes -> kept indices by decreasing score, ties by index (IoU without the
+    reference box_ops' +1e-6: this restates torchvision.ops.nms, which the reference calls).
+    Host formulation for CPU tensors; the checker of the device kernel (tests/test_selftrain_gpu.py)."""
     if boxes.numel() == 0:
         return torch.empty(0, dtype=torch.int64, device=boxes.device)
-    order = scores.argsort(descending=True)
+    order = scores.argsort(descending=True, stable=True)
     b = boxes[order]
     area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
     lt = torch.max(b[:, None, :2], b[None, :, :2])
@@ -75,11 +76,28 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
 
 def batched_nms(boxes, scores, idxs, iou_threshold):
     """Class-aware NMS: boxes of different classes never suppress each other (coordinate
-    offset trick, as torchvision.ops.boxes.batched_nms)."""
+    offset trick, as torchvision.ops.boxes.batched_nms).  Device tensors go through ONE launch of
+    csrc/nms.hip (rank, offsets, IoU and the greedy scan on the device; the same float32
+    arithmetic, so the kept indices equal the host formulation's bit for bit)."""
     if boxes.numel() == 0:
         return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    if boxes.is_cuda:
+        import ctypes  # noqa: F401
+        from . import _native
+        n = boxes.shape[0]
+        b = boxes.detach().contiguous().float()
+        s = scores.detach().contiguous().float()
+        lab = idxs.contiguous().to(torch.int64)
+        keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
+        count = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+        with torch.cuda.device(boxes.device):
+            rc = _native.lib.datr_nms_f32(b.data_ptr(), s.data_ptr(), lab.data_ptr(), n, float(iou_threshold),
+                                          keep.data_ptr(), count.data_ptr(),
+                                          _native.current_stream_ptr(boxes.device))
+        _native.check(rc, "nms")
+        return keep[:int(count.item())]
     offsets = idxs.to(boxes) * (boxes.max() + 1)
-    return nms(boxes + offsets[:, None], scores, iou_threshold)
+    return nms_host(boxes + offsets[:, None], scores, iou_threshold)
 
 
 def rescale_pseudo_targets(unlabel_samples_img, unlabel_pseudo_targets, nms_th=0.7):

@@ -177,6 +177,29 @@ int datr_conv3x3_nhwc_forward_f32(const float *x, const float *wt, const float *
                                   float out_scale, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) convolution on the MFMA units (csrc/wino.hip), exact fp32, NHWC, 3x3 /
+ * stride 1 / pad 1 -- the image-level domain discriminator's layers
+ * (/root/reference/models/dino/DA_utils.py:61-79, call site dino.py:351-359), all pyramid levels in
+ * ONE launch (they share the filter):
+ *   y = out_scale * gate( lrelu_slope( scale[co] * conv3x3(x, W)[.., co] + shift[co] ) )
+ * gate(v) = v where gate_tensor > 0, gate_slope * v elsewhere (gate_tensor may be NULL): the
+ * LeakyReLU backward of the PREVIOUS layer folded into this layer's data gradient.  scale / shift
+ * may be NULL (1 / 0); shift = the bias for the discriminator; slope 1 = no activation;
+ * out_scale = -1 folds the gradient-reversal layer into the first layer's data gradient.
+ * `u` = the transformed filter from datr_wino_weights_f32: [16][Cin/8][2][Cout][4] floats.
+ * Cin % 8 == 0, Cout % 64 == 0.
+ * datr_wino_weights_f32 reads W[co][ci][r][s] at w[co*s_co + ci*s_ci + r*s_r + s*s_s]; for the data
+ * gradient pass the strides of co and ci SWAPPED (Cin, Cout = the gradient's channel counts) and
+ * flip = 1 (taps mirrored). */
+#define DATR_WINO_MAX_LEVELS 4
+typedef struct { const float *x; float *y; const float *gate; int64_t H, W; } datr_wino_level;
+int datr_wino_weights_f32(const float *w, int64_t Cout, int64_t Cin, int64_t s_co, int64_t s_ci,
+                          int64_t s_r, int64_t s_s, int flip, float *u, void *stream);
+int datr_conv3x3_wino_nhwc_f32(const datr_wino_level *levels, int64_t nlevels, int64_t N, int64_t Cin,
+                               int64_t Cout, const float *u, const float *scale, const float *shift,
+                               float slope, float gate_slope, float out_scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * FFN backward, the non-GEMM pass: given h = relu(linear1(x)) saved by the forward and
  * dh = d loss / d h, computes IN PLACE dh <- dh * (h > 0) and db[c] = sum_r dh[r, c]
  * (the bias gradient of linear1) in one pass over HBM
@@ -268,6 +291,17 @@ int datr_box_loss_backward_f32(const float *src, const float *tgt, const int64_t
  * k > 1024: DATR_EUNSUPPORTED. */
 int datr_topk_rows_f32(const float *scores, int64_t rows, int64_t n, int64_t k, int64_t *out_idx,
                        float *out_val, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Class-aware greedy NMS of the teacher's pseudo labels (csrc/nms.hip):
+ * `torchvision.ops.batched_nms(boxes, scores, labels, thr)` as called by rescale_pseudo_targets
+ * (/root/reference/models/dino/self_training_utils.py:80-83; torchvision is un-vendored: classes
+ * are separated by adding label * (max coordinate + 1) to the xyxy boxes, IoU > thr suppresses).
+ * boxes [n, 4] xyxy, scores [n], labels [n] int64, n <= 4096.  keep [n] receives the surviving
+ * ORIGINAL indices in decreasing score order (ties: lower index first), *count their number.
+ * Bit-identical to the float32 host formulation (no FMA contraction). */
+int datr_nms_f32(const float *boxes, const float *scores, const int64_t *labels, int64_t n,
+                 float iou_threshold, int64_t *keep, int32_t *count, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sine embedding of the decoder's reference boxes: `gen_sineembed_for_position`

@@ -125,3 +125,15 @@ def test_ema_update_of_aliased_heads_follows_the_per_key_loop():
     k = "class_embed.0.weight"
     single = expect[k] * d + (1 - d) * msd[k]
     assert float((teacher.ema.state_dict()[k] - expect[k]).norm()) > 5 * float((single - expect[k]).norm())
+
+
+def test_host_nms_hand_computed_case():
+    """Three overlapping boxes of one class and one of another: IoU(0,1) = 0.81 > 0.7 suppresses the
+    lower-scored of the two, IoU(0,2) = 0.43 does not; the other class is never touched."""
+    from datr_amd.self_training import batched_nms
+    boxes = torch.tensor([[0., 0., 10., 10.], [1., 0., 11., 10.], [4., 0., 14., 10.], [0., 0., 10., 10.]])
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.6])
+    labels = torch.tensor([1, 1, 1, 2])
+    assert batched_nms(boxes, scores, labels, 0.7).tolist() == [0, 2, 3]
+    assert batched_nms(boxes, scores, labels, 0.4).tolist() == [0, 3]
+    assert batched_nms(boxes, torch.tensor([0.5, 0.5, 0.5, 0.5]), labels, 0.7).tolist() == [0, 2, 3]

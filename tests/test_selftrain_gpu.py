@@ -57,3 +57,35 @@ def test_teacher_student_step_on_device():
     sd = model.state_dict()
     norms = np.array([float(sd[str(k)].double().norm()) for k in g["param_keys"]])
     np.testing.assert_allclose(norms, g["param_norms"], rtol=5e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,classes", [(1, 1), (7, 2), (100, 8), (900, 3)])
+def test_device_nms_keeps_exactly_the_host_indices(n, classes):
+    """csrc/nms.hip (rank + class offsets + IoU + greedy scan in one launch) against the float32 host
+    formulation of torchvision's batched_nms (self_training.nms_host): identical kept indices in
+    identical order, on crowded boxes (clusters of near-duplicates), tied scores and IoUs sitting
+    next to the 0.7 threshold."""
+    from datr_amd.self_training import batched_nms
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    centres = torch.rand(max(n // 6, 1), 2, generator=g) * 900 + 100
+    pick = torch.randint(0, centres.shape[0], (n,), generator=g)
+    cxcy = centres[pick] + torch.randn(n, 2, generator=g) * 6
+    wh = 80 + torch.rand(n, 2, generator=g) * 40
+    boxes = torch.cat([cxcy - wh / 2, cxcy + wh / 2], 1)
+    scores = (torch.rand(n, generator=g) * 20).round() / 20          # many exact ties
+    labels = torch.randint(1, classes + 1, (n,), generator=g)
+    for thr in (0.7, 0.5):
+        host = batched_nms(boxes, scores, labels, thr)
+        mine = batched_nms(boxes.to(dev), scores.to(dev), labels.to(dev), thr)
+        assert mine.dtype == torch.int64 and torch.equal(mine.cpu(), host)
+    if n >= 100:
+        assert 0 < host.numel() < n
+
+
+def test_device_nms_of_no_boxes_is_empty():
+    from datr_amd.self_training import batched_nms
+    dev = torch.device("cuda:0")
+    out = batched_nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev),
+                      torch.zeros(0, dtype=torch.int64, device=dev), 0.7)
+    assert out.shape == (0,) and out.dtype == torch.int64

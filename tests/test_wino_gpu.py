@@ -1,0 +1,89 @@
+"""csrc/wino.hip (Winograd F(2x2,3x3) on the MFMA units) and the discriminator path built on it,
+against float64 convolutions under autograd (DA_utils.py:33-79 semantics)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("cin,cout,sizes", [
+    (8, 64, [(5, 7)]),
+    (16, 64, [(16, 16), (17, 33)]),
+    (128, 128, [(25, 42), (13, 21), (1, 1), (2, 3)]),
+    (256, 128, [(50, 84), (7, 11)]),
+])
+def test_wino_conv_forward_and_data_gradient_match_float64(cin, cout, sizes):
+    """Forward (scale, shift, LeakyReLU) and the transposed-filter call (gate, out_scale) of
+    wino_conv3x3 vs F.conv2d / its autograd data gradient in float64; ragged sizes exercise the zero
+    padding and the partial tiles, several levels share one launch."""
+    from datr_amd.domain import wino_conv3x3, wino_filter
+    dev = torch.device("cuda:0")
+    torch.manual_seed(cin + cout)
+    N = 2
+    w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
+    shift = torch.randn(cout, device=dev)
+    scale = torch.rand(cout, device=dev) + 0.5
+    xs = [_cl(torch.randn(N, cin, h, ww, device=dev)) for h, ww in sizes]
+    ys = wino_conv3x3(xs, wino_filter(w), cout, shift=shift, scale=scale, slope=0.2)
+    for x, y in zip(xs, ys):
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        ref = F.leaky_relu(F.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1)
+                           + shift.double().view(1, -1, 1, 1), 0.2)
+        torch.testing.assert_close(y.double(), ref, rtol=2e-5, atol=2e-5)
+    # data gradient with a gate and the reversal sign: needs cin % 64 == 0 as the gradient's Cout
+    if cin % 64 == 0:
+        dys = [_cl(torch.randn(N, cout, h, ww, device=dev)) for h, ww in sizes]
+        gates = [_cl(torch.randn(N, cin, h, ww, device=dev)) for h, ww in sizes]
+        dxs = wino_conv3x3(dys, wino_filter(w, True), cin, gates=gates, gate_slope=0.2, out_scale=-1.0)
+        for x, dy, g, dx in zip(xs, dys, gates, dxs):
+            xd = x.double().requires_grad_(True)
+            (gx,) = torch.autograd.grad(F.conv2d(xd, w.double(), padding=1), xd, dy.double())
+            ref = -torch.where(g.double() > 0, gx, gx * 0.2)
+            torch.testing.assert_close(dx.double(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_wino_filter_handles_channels_last_weights():
+    from datr_amd.domain import wino_filter
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    w = torch.randn(64, 16, 3, 3, device=dev)
+    for dg in (False, True):
+        if dg and w.shape[1] % 64:
+            continue
+        assert torch.equal(wino_filter(w, dg), wino_filter(_cl(w), dg))
+
+
+@pytest.mark.parametrize("sizes", [[(20, 27), (10, 14), (5, 7), (3, 4)], [(33, 18)]])
+def test_discriminator_pyramid_matches_library_convolutions(sizes, monkeypatch):
+    """FCDiscriminator_img.reversed_pyramid (GRL + 4 convs, own Winograd path) against the same
+    module on float64 library convolutions under autograd: logits, every parameter gradient and the
+    (reversed) input gradients; the input gradients of two backward runs are bitwise identical."""
+    from datr_amd import domain
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    d = domain.FCDiscriminator_img(256).to(dev)
+    xs = [torch.randn(2, 256, h, w, device=dev, requires_grad=True) for h, w in sizes]
+    gos = [torch.randn(2, 1, h, w, device=dev) for h, w in sizes]
+    assert domain.OWN_D_IMG
+    outs = d.reversed_pyramid(xs)
+    params = list(d.parameters())
+    grads = torch.autograd.grad(outs, params + xs, gos, retain_graph=True)
+    grads2 = torch.autograd.grad(outs, params + xs, gos)
+    for a, b in zip(grads[len(params):], grads2[len(params):]):    # own kernels: bitwise reproducible
+        assert torch.equal(a, b)                                   # (the library's weight gradient is not)
+
+    d64 = domain.FCDiscriminator_img(256).to(dev).double()
+    d64.load_state_dict({k: v.double() for k, v in d.state_dict().items()})
+    xs64 = [x.detach().double().requires_grad_(True) for x in xs]
+    monkeypatch.setattr(domain, "OWN_D_IMG", False)
+    outs64 = d64.reversed_pyramid(xs64)
+    ref = torch.autograd.grad(outs64, list(d64.parameters()) + xs64, [g.double() for g in gos])
+    for o, r in zip(outs, outs64):
+        torch.testing.assert_close(o.double(), r, rtol=1e-4, atol=1e-4)
+    for g, r in zip(grads, ref):
+        torch.testing.assert_close(g.double(), r, rtol=1e-4, atol=1e-4 * max(1.0, float(r.abs().max())))
