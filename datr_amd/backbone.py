@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .fused import frozen_bn_act
+from .wino import conv3x3_bn_relu
 from .nested import NestedTensor
 
 
@@ -92,7 +93,11 @@ class Bottleneck(nn.Module):
             identity = frozen_bn_act(self.downsample[0](x), *self.downsample[1].scale_shift(),
                                      relu=False)
         out = frozen_bn_act(self.conv1(x), *self.bn1.scale_shift(), relu=True)
-        out = frozen_bn_act(self.conv2(out), *self.bn2.scale_shift(), relu=True)
+        out2 = None
+        if self.conv2.stride == (1, 1):
+            # 3x3 / stride 1 + frozen BN + ReLU: one Winograd/MFMA launch (csrc/wino.hip)
+            out2 = conv3x3_bn_relu(out, self.conv2.weight, *self.bn2.scale_shift())
+        out = out2 if out2 is not None else frozen_bn_act(self.conv2(out), *self.bn2.scale_shift(), relu=True)
         return frozen_bn_act(self.conv3(out), *self.bn3.scale_shift(), residual=identity, relu=True)
 
 

@@ -9,13 +9,14 @@ so values agree to fp32 rounding, the argmax class map and counts are exact.
 """
 from __future__ import annotations
 
-import ctypes
 import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 from torch.autograd.function import once_differentiable
+
+from .wino import _nhwc, wino_conv3x3, wino_filter
 
 # own Winograd-on-MFMA path for the discriminator's 3x3 convolutions (csrc/wino.hip); 0 = the
 # library convolutions under autograd (A/B measurements)
@@ -42,56 +43,6 @@ class GradReverse(torch.autograd.Function):
 
 def grad_reverse(x):
     return GradReverse.apply(x)
-
-
-def _nhwc(x: torch.Tensor) -> torch.Tensor:
-    return x.contiguous(memory_format=torch.channels_last)
-
-
-def wino_filter(w: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
-    """Winograd-domain filter G g G^T of a [Cout, Cin, 3, 3] weight in the layout csrc/wino.hip reads
-    ([16][Cin/8][2][Cout][4]); data_gradient=True gives the filter of the transposed convolution
-    (channels swapped, taps mirrored)."""
-    from . import _native
-    co, ci = w.shape[:2]
-    s = w.stride()
-    if data_gradient:
-        co, ci, s = ci, co, (s[1], s[0], s[2], s[3])
-    u = torch.empty(16 * ci * co, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
-        rc = _native.lib.datr_wino_weights_f32(w.data_ptr(), co, ci, s[0], s[1], s[2], s[3],
-                                               1 if data_gradient else 0, u.data_ptr(),
-                                               _native.current_stream_ptr(w.device))
-    _native.check(rc, "wino_weights")
-    return u
-
-
-def wino_conv3x3(xs, u: torch.Tensor, cout: int, shift=None, scale=None, slope: float = 1.0, gates=None,
-                 gate_slope: float = 1.0, out_scale: float = 1.0):
-    """3x3 / stride 1 / pad 1 convolution of every level in `xs` (channels_last [N, Cin, H, W] device
-    tensors sharing the filter `u` from wino_filter) in ONE launch of csrc/wino.hip:
-    out = out_scale * gate(lrelu_slope(scale * conv + shift)); returns channels_last tensors."""
-    from . import _native
-    assert 1 <= len(xs) <= 4
-    N, cin = xs[0].shape[:2]
-    ys = [torch.empty((N, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32,
-                      memory_format=torch.channels_last) for x in xs]
-    levels = (_native.WinoLevel * len(xs))()
-    for i, (x, y) in enumerate(zip(xs, ys)):
-        assert x.is_cuda and x.dtype == torch.float32 and x.shape[:2] == (N, cin)
-        assert x.is_contiguous(memory_format=torch.channels_last)
-        g = None if gates is None else gates[i]
-        if g is not None:
-            assert g.shape == y.shape and g.is_contiguous(memory_format=torch.channels_last)
-        levels[i] = _native.WinoLevel(x.data_ptr(), y.data_ptr(), 0 if g is None else g.data_ptr(),
-                                      x.shape[2], x.shape[3])
-    with torch.cuda.device(xs[0].device):
-        rc = _native.lib.datr_conv3x3_wino_nhwc_f32(
-            ctypes.addressof(levels), len(xs), N, cin, cout, u.data_ptr(),
-            0 if scale is None else scale.data_ptr(), 0 if shift is None else shift.data_ptr(),
-            slope, gate_slope, out_scale, _native.current_stream_ptr(xs[0].device))
-    _native.check(rc, "conv3x3_wino_nhwc")
-    return ys
 
 
 class _DImgPyramid(torch.autograd.Function):

@@ -87,3 +87,56 @@ def test_discriminator_pyramid_matches_library_convolutions(sizes, monkeypatch):
         torch.testing.assert_close(o.double(), r, rtol=1e-4, atol=1e-4)
     for g, r in zip(grads, ref):
         torch.testing.assert_close(g.double(), r, rtol=1e-4, atol=1e-4 * max(1.0, float(r.abs().max())))
+
+
+@pytest.mark.parametrize("c,hw,trainable", [(64, (40, 52), False), (128, (25, 42), True), (256, (13, 21), True)])
+def test_conv3x3_bn_relu_matches_float64(c, hw, trainable, monkeypatch):
+    """datr_amd.wino.conv3x3_bn_relu (conv2 + frozen BN + ReLU of a ResNet bottleneck as ONE
+    Winograd/MFMA launch; backward = fused gate pass, own data gradient, library weight gradient)
+    against float64 ops.  The reference gradient uses the ReLU mask of the kernel's own output, so a
+    pre-activation within rounding of zero cannot flip the comparison."""
+    from datr_amd import wino
+    from datr_amd.wino import conv3x3_bn_relu
+    monkeypatch.setattr(wino, "OWN_BACKBONE_3X3_MAX_CH", 4096)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(c)
+    w = (torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)).contiguous(memory_format=torch.channels_last)
+    w.requires_grad_(trainable)
+    scale, shift = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
+    x = torch.randn(2, c, *hw, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(trainable)
+    y = conv3x3_bn_relu(x, w, scale, shift)
+    assert y is not None and y.is_contiguous(memory_format=torch.channels_last)
+    z = F.conv2d(x.detach().double(), w.detach().double(), padding=1) * scale.double().view(1, -1, 1, 1) \
+        + shift.double().view(1, -1, 1, 1)
+    torch.testing.assert_close(y.detach().double(), z.clamp(min=0), rtol=2e-5, atol=2e-5)
+    assert conv3x3_bn_relu(x.detach().contiguous(), w, scale, shift) is None          # NCHW: library path
+    if not trainable:
+        return
+    go = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, (x, w), go)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    zd = F.conv2d(xd, wd, padding=1)
+    dz = go.double() * (y.detach() > 0) * scale.double().view(1, -1, 1, 1)
+    rx, rw = torch.autograd.grad(zd, (xd, wd), dz)
+    torch.testing.assert_close(gx.double(), rx, rtol=1e-4, atol=1e-4 * float(rx.abs().max()))
+    torch.testing.assert_close(gw.double(), rw, rtol=1e-4, atol=1e-4 * float(rw.abs().max()))
+
+
+def test_backbone_bottleneck_routes_conv2_through_the_own_kernel(monkeypatch):
+    """A channels_last bottleneck gives the same output with conv2 + bn2 + relu on the own kernel as
+    on the library convolution + fused frozen-BN pass, and really calls the kernel."""
+    from datr_amd import backbone, wino
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    blk = backbone.Bottleneck(512, 128, 1, backbone.FrozenBatchNorm2d, downsample=False).to(dev)
+    blk = blk.to(memory_format=torch.channels_last)
+    x = torch.randn(2, 512, 25, 42, device=dev).contiguous(memory_format=torch.channels_last)
+    calls = []
+    real = wino.wino_conv3x3
+    monkeypatch.setattr(wino, "wino_conv3x3", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        y_own = blk(x)
+        assert calls
+        monkeypatch.setattr(wino, "OWN_BACKBONE_3X3", False)
+        y_lib = blk(x)
+    torch.testing.assert_close(y_own, y_lib, rtol=1e-4, atol=1e-4)

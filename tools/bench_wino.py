@@ -61,3 +61,31 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def backbone_layers():
+    """conv2 + frozen BN + ReLU of the ResNet-50 bottlenecks at 4 x 1333x800 (stride-1 blocks):
+    own Winograd/MFMA launch vs library convolution + fused frozen-BN pass, forward and fwd+bwd."""
+    from datr_amd import wino
+    from datr_amd.fused import frozen_bn_act
+    dev = torch.device("cuda:0")
+    for c, h, w_, n_blocks, train in ((64, 200, 334, 3, False), (128, 100, 167, 3, True), (256, 50, 84, 5, True),
+                                      (512, 25, 42, 2, True)):
+        wt = (torch.randn(c, c, 3, 3, device=dev) * 0.02).contiguous(memory_format=torch.channels_last)
+        wt.requires_grad_(train)
+        scale, shift = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
+        x = torch.randn(4, c, h, w_, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(train)
+        go = torch.randn(4, c, h, w_, device=dev).contiguous(memory_format=torch.channels_last)
+        own = lambda: wino.conv3x3_bn_relu(x, wt, scale, shift)
+        lib = lambda: frozen_bn_act(torch.nn.functional.conv2d(x, wt, padding=1), scale, shift, relu=True)
+        row = f"backbone conv2 {c}ch @{h}x{w_} (x{n_blocks}/step):"
+        for name, fn in (("own", own), ("library", lib)):
+            with torch.no_grad():
+                t_f = timed(fn, 10)
+            t_fb = timed(lambda: torch.autograd.grad(fn(), (x, wt), go), 10) if train else float("nan")
+            row += f"  {name} fwd {t_f * 1e3:.0f} us, fwd+bwd {t_fb * 1e3:.0f} us;"
+        print(row)
+
+
+if __name__ == "__main__" and os.environ.get("BENCH_BACKBONE", "1") != "0":
+    backbone_layers()
