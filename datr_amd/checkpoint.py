@@ -57,3 +57,22 @@ def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, arg
 def save_ema_checkpoint(path, ema_model, epoch):
     """best_ema_teacher.pth / best_ema_model.pth layout (main.py:487-507)."""
     torch.save({"ema_model": ema_model.state_dict(), "epoch": epoch}, path)
+
+
+def resume(checkpoint, model, optimizer=None, lr_scheduler=None, ema_model=None, eval_only: bool = False) -> int:
+    """The reference's `--resume` block (main.py:226-245): model weights from 'model' (strict), the
+    EMA copy from 'ema_model' with the DDP prefix stripped when both exist, and -- unless evaluating
+    -- optimizer, scheduler and epoch when all three are present.  Returns the epoch to start from
+    (`checkpoint['epoch'] + 1`, or 0)."""
+    if isinstance(checkpoint, (str, bytes)):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    model.load_state_dict(clean_state_dict(checkpoint["model"]))
+    if ema_model is not None and "ema_model" in checkpoint:
+        ema_model.load_state_dict(clean_state_dict(checkpoint["ema_model"]))
+    start_epoch = 0
+    if (not eval_only and optimizer is not None and lr_scheduler is not None
+            and all(k in checkpoint for k in ("optimizer", "lr_scheduler", "epoch"))):
+        optimizer.load_state_dict(checkpoint["optimizer"])
+        lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
+        start_epoch = checkpoint["epoch"] + 1
+    return start_epoch
