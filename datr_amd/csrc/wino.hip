@@ -9,28 +9,40 @@
 //   multiplies than the direct form; MIOpen's fp32 kernel for these layers is the same algorithm on
 //   the VALU, this one runs the 16 per-position channel contractions as v_mfma_f32_32x32x2_f32).
 //
-// Work split: a workgroup = 8 x 8 tiles (16 x 16 output pixels) x 64 output channels; wave (a, b)
-// owns tiles 32 a .. 32 a + 31 and channels 32 b .. 32 b + 31 for ALL 16 transform positions: 16
-// accumulator blocks = 256 AGPRs, so the inverse transform A^T M A is lane-local (no exchange) and a
-// lane's 32-lane row stores 128 contiguous bytes of NHWC output.  Input channels go by in chunks of
-// 8, software-pipelined with ONE barrier per chunk: while chunk c is multiplied, the raw 18 x 18
-// patch of chunk c + 1 (staged in LDS, zero outside the image) is turned into V = B^T d B -- each
-// thread owns (tile, 4 channels, 2 of the 4 transform rows), a sixteenth of that work is issued
-// between the MFMAs of each position -- the transformed filter slab of chunk c + 1 (32 KB,
-// [pos][k-half][cout][4] so that every ds_read_b128 group is bank-conflict free) arrives by LDS-DMA,
-// the raw patch of chunk c + 2 is written to LDS and that of chunk c + 3 is in flight in registers.
-// All levels of the pyramid share the filter, so they are ONE launch (level table in the arguments).
+// Work split: a workgroup = 8 x 8 tiles (16 x 16 output pixels) x 64 output channels, 8 waves.
+// Wave (wp, wa, wb) owns tiles 32 wa .. + 31 and channels 32 wb .. + 31 for the transform rows
+// xi = 2 wp, 2 wp + 1 (8 of the 16 positions = 8 accumulator blocks = 128 registers; the two waves
+// of a SIMD hold the two halves).  The inverse transform A^T M A is lane-local up to one exchange of
+// 32 floats per lane between the two position halves (through LDS, once per workgroup), and a lane's
+// 32-lane row stores 128 contiguous bytes of NHWC output.  Input channels go by in chunks of 8,
+// software-pipelined with ONE barrier per chunk: while chunk c is multiplied, the raw 18 x 18 patch
+// of chunk c + 1 (staged in LDS, zero outside the image) is turned into V = B^T d B -- each thread
+// owns (tile, 4 channels, 2 of the 4 transform rows, 2 of the 4 columns), a piece of that work is
+// issued between the MFMAs of each position pair -- the transformed filter slab of chunk c + 1
+// (32 KB, [pos][k-half][cout][4] so that every ds_read_b128 group is bank-conflict free) arrives by
+// LDS-DMA, the raw patch of chunk c + 2 is written to LDS and that of chunk c + 3 is in flight in
+// registers.  All levels of the pyramid share the filter, so they are ONE launch (level table in the
+// arguments).
+//
+// Measured (profiles/r02_wino.md): 256 -> 256 on the 100 x 167 level of 4 images 492 us = 160 TF/s
+// direct-equivalent (MIOpen's fp32 Winograd: 785 us); the MFMA stream alone (copies, transform,
+// operand reads compiled out) runs 352 us -- the rest is VALU / LDS / vector-memory ISSUE competing
+// with the MFMAs for the SIMD's issue port, the same with one or two waves per SIMD.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 
 #include "datr_hip.h"
 
+#ifndef WINO_ABLATE
+#define WINO_ABLATE 0      // development only (wrong results): 1 no copies, 2 no transform, 4 no operand reads, 8 no loop barrier
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;                 // 8 waves: two per SIMD share the 16 transform positions
 constexpr int TB = 8;                          // tiles per workgroup edge
 constexpr int PW = 2 * TB + 2;                 // patch edge (18)
 constexpr int PPIX = PW * PW;                  // 324
@@ -56,9 +68,12 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
     float *Vs = patch + 2 * kPatchF;           // [2 buffers][16][2][64][4]
     float *Bs = Vs + 2 * kVF;                  // [2 buffers][16][2][64][4]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int wa = wave >> 1, wb = wave & 1;
+    // wave = (wp, wa, wb): transform rows 2 wp, 2 wp + 1 (positions 8 wp .. 8 wp + 7) of tiles
+    // 32 wa .. + 31 and output channels 32 wb .. + 31; waves w and w + 4 share a SIMD
+    const int wp = wave >> 2, wa = (wave >> 1) & 1, wb = wave & 1;
 
     // ---- which level / image / tile block ------------------------------------------------------
     int lvl = 0;
@@ -75,35 +90,34 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
     const int co0 = blockIdx.y * BN;
     const float *Xn = L.x + (size_t)n * H * W * Cin;
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
 
     // filter slab of chunk c -> Bs[buf]: per (pos, half) 64 couts x 16 B = 1 KiB contiguous in
-    // U[pos][Cin/8][2][Cout][4]; 32 pieces, 8 per wave, one LDS-DMA instruction each
+    // U[pos][Cin/8][2][Cout][4]; 32 pieces, 4 per wave, one LDS-DMA instruction each.  (Inline asm,
+    // not the builtin: the compiler would make every later ds_read wait for the DMA -- vmcnt(0)
+    // right after issue; completion is awaited explicitly before the chunk's closing barrier.)
     const int nchunks = Cin / CK;
-    // (inline asm, not the builtin: the compiler would make every later ds_read wait for the DMA --
-    // vmcnt(0) right after issue -- and serialise the copy with the multiplication it should hide
-    // behind; completion is awaited explicitly before the chunk's closing barrier)
     const unsigned bs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float *)Bs;
     auto dma_b = [&](int c, int buf) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int piece = wave * 8 + u;                    // = pos * 2 + half
+        for (int u = 0; u < 4; ++u) {
+            const int piece = wave * 4 + u;                    // = pos * 2 + half
             const int pos = piece >> 1, half = piece & 1;
             const float *src = U + ((((size_t)pos * nchunks + c) * 2 + half) * Cout + co0 + lane) * 4;
             const unsigned dst = __builtin_amdgcn_readfirstlane(bs_lds + (buf * kBF + piece * BN * 4) * 4);
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory");
         }
     };
-    // raw patch of chunk c: 324 pixels x 2 float4, zero outside the image; register-staged so that
-    // the loads of chunk c + 1 are in flight while chunk c is multiplied
-    float4 pf[3];
+    // raw patch of chunk c: 324 pixels x 2 float4 (648 <= 2 x 512), zero outside the image;
+    // register-staged so that the loads of chunk c + 3 are in flight while chunk c is multiplied
+    float4 pf[2];
     auto fetch_patch = [&](int c) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int f = tid + u * kThreads;
             const int pix = f >> 1, h = f & 1;
             const int py = pix / PW, px = pix - py * PW;
@@ -116,56 +130,52 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
     };
     auto store_patch = [&](float *dst) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int f = tid + u * kThreads;
             const int pix = f >> 1, h = f & 1;
             if (f < 2 * PPIX) *reinterpret_cast<float4 *>(&dst[(h * PPIX + pix) * 4]) = pf[u];
         }
     };
 
-    // transform unit of this thread: (tile, channel half, pair of transform rows); the pair is
-    // wave-uniform (waves 0,1: rows 0,1 from patch rows 0-2; waves 2,3: rows 2,3 from patch rows 1-3)
-    const int t_tile = tid & 63, t_half = (tid >> 6) & 1;
-    const int t_pair = __builtin_amdgcn_readfirstlane(tid >> 7);
+    // transform unit of this thread: (tile, channel half, pair of transform rows, pair of transform
+    // columns); everything but the tile is wave-uniform.  Row pair q: rows 0,1 from patch rows 0-2,
+    // rows 2,3 from patch rows 1-3; column pair likewise from patch columns 0-2 / 1-3.
+    const int t_tile = tid & 63;
+    const int t_half = wave & 1, t_rp = (wave >> 1) & 1, t_cp = wave >> 2;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    const int p_off = (t_half * PPIX + (2 * t_ty + t_pair) * PW + 2 * t_tx) * 4;
-    const int v_off = (((t_pair * 2 * 4) * 2 + t_half) * 64 + t_tile) * 4;          // xi = 2 pair, nu = 0
+    const int p_off = (t_half * PPIX + (2 * t_ty + t_rp) * PW + 2 * t_tx + t_cp) * 4;
     constexpr int kVPos = 2 * 64 * 4;          // floats between consecutive positions of V / a filter slab
+    const int v_off = ((((t_rp * 2) * 4 + t_cp * 2) * 2 + t_half) * 64 + t_tile) * 4;   // (xi, nu) = (2 rp, 2 cp)
 
-    float4 d[3][4], tq[4];
-    auto tr_load = [&](const float *pb, int k) {               // two of the 12 raw patch float4
+    float4 d[3][3], tq[3];
+    auto tr_load = [&](const float *pb, int rr) {              // one row of the 3 x 3 raw float4
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int rr = (2 * k + u) >> 2, cc = (2 * k + u) & 3;
+        for (int cc = 0; cc < 3; ++cc)
             d[rr][cc] = *reinterpret_cast<const float4 *>(pb + p_off + (rr * PW + cc) * 4);
-        }
     };
-    auto tr_rows = [&](int q) {                                // t = (B^T d) row xi = 2 pair + q
+    auto tr_rows = [&](int q) {                                // t = (B^T d) row xi = 2 rp + q
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            if (t_pair == 0) tq[cc] = q == 0 ? f4sub(d[0][cc], d[2][cc]) : f4add(d[1][cc], d[2][cc]);
-            else             tq[cc] = q == 0 ? f4sub(d[1][cc], d[0][cc]) : f4sub(d[0][cc], d[2][cc]);
+        for (int cc = 0; cc < 3; ++cc) {
+            if (t_rp == 0) tq[cc] = q == 0 ? f4sub(d[0][cc], d[2][cc]) : f4add(d[1][cc], d[2][cc]);
+            else           tq[cc] = q == 0 ? f4sub(d[1][cc], d[0][cc]) : f4sub(d[0][cc], d[2][cc]);
         }
     };
-    auto tr_store = [&](float *vbuf, int q, int hi) {          // V[xi][2 hi], V[xi][2 hi + 1] = (t B)
-        float *vb = vbuf + v_off + q * 4 * kVPos + hi * 2 * kVPos;
-        if (hi == 0) {
+    auto tr_store = [&](float *vbuf, int q) {                  // V[xi][2 cp], V[xi][2 cp + 1] = (t B)
+        float *vb = vbuf + v_off + q * 4 * kVPos;
+        if (t_cp == 0) {
             *reinterpret_cast<float4 *>(vb) = f4sub(tq[0], tq[2]);
             *reinterpret_cast<float4 *>(vb + kVPos) = f4add(tq[1], tq[2]);
         } else {
-            *reinterpret_cast<float4 *>(vb) = f4sub(tq[2], tq[1]);
-            *reinterpret_cast<float4 *>(vb + kVPos) = f4sub(tq[1], tq[3]);
+            *reinterpret_cast<float4 *>(vb) = f4sub(tq[1], tq[0]);
+            *reinterpret_cast<float4 *>(vb + kVPos) = f4sub(tq[0], tq[2]);
         }
     };
-    // slot k of 16: a 16th of the transform of one chunk (12 loads, 2 x (rows, 2 stores))
-    auto tr_piece = [&](const float *pb, float *vbuf, int k) {
-        if (k < 6) tr_load(pb, k);
-        else if (k == 6) tr_rows(0);
-        else if (k == 7) tr_store(vbuf, 0, 0);
-        else if (k == 8) tr_store(vbuf, 0, 1);
-        else if (k == 9) tr_rows(1);
-        else if (k == 10) tr_store(vbuf, 1, 0);
-        else if (k == 11) tr_store(vbuf, 1, 1);
+    auto tr_piece = [&](const float *pb, float *vbuf, int k) { // 7 pieces
+        if (k < 3) tr_load(pb, k);
+        else if (k == 3) tr_rows(0);
+        else if (k == 4) tr_store(vbuf, 0);
+        else if (k == 5) tr_rows(1);
+        else if (k == 6) tr_store(vbuf, 1);
     };
 
     // ---- prologue: patches 0, 1 in LDS, patch 2 in registers, slab 0 on its way, V(0) computed ------
@@ -176,49 +186,98 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
     if (nchunks > 2) fetch_patch(2);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 12; ++k) tr_piece(patch, Vs, k);
+    for (int k = 0; k < 7; ++k) tr_piece(patch, Vs, k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int a_off = (lhi * 64 + wa * 32 + l31) * 4;
-    const int b_off = (lhi * BN + wb * 32 + l31) * 4;
+    const int a_off = (wp * 8 * 2 * 64 + lhi * 64 + wa * 32 + l31) * 4;
+    const int b_off = (wp * 8 * 2 * BN + lhi * BN + wb * 32 + l31) * 4;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         // invariant: V[buf], Bs[buf] hold chunk c; patch[buf ^ 1] holds the raw chunk c + 1; the
         // registers hold the raw chunk c + 2; every wave is past its reads of chunk c - 1
-        if (c + 2 < nchunks) store_patch(patch + buf * kPatchF);
-        if (c + 3 < nchunks) fetch_patch(c + 3);
         const bool more = c + 1 < nchunks;
-        if (more) dma_b(c + 1, buf ^ 1);
+        auto copies = [&]() {                  // this wave's share of the chunk's global traffic
+            if (c + 2 < nchunks) store_patch(patch + buf * kPatchF);
+            if (c + 3 < nchunks) fetch_patch(c + 3);
+            if (more) dma_b(c + 1, buf ^ 1);
+        };
+        // the two waves of a SIMD issue their copies at different points of the chunk, so the
+        // issue stall of one (an LDS-DMA piece costs ~100 cycles) hides behind the other's MFMAs
+        if (!(WINO_ABLATE & 1) && wp == 0) copies();
 
-        // 16 positions x (32 tiles x 32 couts) += V[pos] U[pos] over the 8 channels of chunk c, with the
-        // transform of chunk c + 1 issued in the shadow of the MFMAs (one sixteenth per position)
+        // 8 positions x (32 tiles x 32 couts) += V[pos] U[pos] over the 8 channels of chunk c, with
+        // this thread's share of the transform of chunk c + 1 issued in the shadow of the MFMAs.
+        // Issue order (pinned with sched_barriers): two positions per slot, their MFMAs ALTERNATE so
+        // that back-to-back MFMAs never share an accumulator.
         const float *va = Vs + buf * kVF + a_off;
         const float *vbs = Bs + buf * kBF + b_off;
         const float *pnext = patch + (buf ^ 1) * kPatchF;
         float *vnext = Vs + (buf ^ 1) * kVF;
-        float4 a4 = *reinterpret_cast<const float4 *>(va);
-        float4 b4 = *reinterpret_cast<const float4 *>(vbs);
+        float4 a0 = *reinterpret_cast<const float4 *>(va), b0 = *reinterpret_cast<const float4 *>(vbs);
+        float4 a1 = *reinterpret_cast<const float4 *>(va + kVPos), b1 = *reinterpret_cast<const float4 *>(vbs + kVPos);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            float4 an = a4, bn = b4;
-            if (p < 15) {
-                an = *reinterpret_cast<const float4 *>(va + (p + 1) * kVPos);
-                bn = *reinterpret_cast<const float4 *>(vbs + (p + 1) * kVPos);
-            }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[p], 0, 0, 0);
-            if (more) tr_piece(pnext, vnext, p);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[p], 0, 0, 0);
+        for (int sl = 0; sl < 4; ++sl) {
+            const int p0 = 2 * sl, p1 = 2 * sl + 1, nx = (sl < 3 ? 2 * sl + 2 : 0);
+            float4 an0, bn0, an1, bn1;
+            if (!(WINO_ABLATE & 1) && sl == 2 && wp == 1) copies();
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[p0], 0, 0, 0);
+            an0 = (WINO_ABLATE & 4) ? a0 : *reinterpret_cast<const float4 *>(va + nx * kVPos);
             __builtin_amdgcn_sched_barrier(0);
-            a4 = an; b4 = bn;
+            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[p1], 0, 0, 0);
+            bn0 = (WINO_ABLATE & 4) ? b0 : *reinterpret_cast<const float4 *>(vbs + nx * kVPos);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[p0], 0, 0, 0);
+            an1 = (WINO_ABLATE & 4) ? a1 : *reinterpret_cast<const float4 *>(va + (nx + 1) * kVPos);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[p1], 0, 0, 0);
+            bn1 = (WINO_ABLATE & 4) ? b1 : *reinterpret_cast<const float4 *>(vbs + (nx + 1) * kVPos);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[p0], 0, 0, 0);
+            if (!(WINO_ABLATE & 2) && more) tr_piece(pnext, vnext, 2 * sl);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[p1], 0, 0, 0);
+            if (!(WINO_ABLATE & 2) && more) tr_piece(pnext, vnext, 2 * sl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[p0], 0, 0, 0);
+            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[p1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = an0; b0 = bn0; a1 = an1; b1 = bn1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab c + 1 (this wave's pieces) landed
-        __syncthreads();
+        if (!(WINO_ABLATE & 8)) __syncthreads();
     }
 
-    // ---- inverse transform + epilogue, lane-local: lane = cout, register e = tile ------------------
+    // ---- inverse transform: lane = cout, register e = tile.  This wave holds transform rows
+    // xi = 2 wp, 2 wp + 1: T[xi][j] = (M A)[xi][j], and its share of Y = A^T T is
+    //   wp 0: Y[0][j] += T[0][j] + T[1][j], Y[1][j] += T[1][j];   wp 1: Y[0][j] += T[2][j], Y[1][j] += -T[2][j] - T[3][j].
+    // Wave wp finishes output row i = wp of every tile: the partial of the OTHER row goes to the
+    // partner wave (same wa, wb) through LDS (the filter slabs' space; 32 floats per lane).
+    float mine[2][16], other[2][16];           // [j][e]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float t[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float m0 = acc[q * 4][e], m1 = acc[q * 4 + 1][e], m2 = acc[q * 4 + 2][e], m3 = acc[q * 4 + 3][e];
+            t[q][0] = m0 + m1 + m2;
+            t[q][1] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (wp == 0) { mine[j][e] = t[0][j] + t[1][j]; other[j][e] = t[1][j]; }
+            else         { mine[j][e] = -t[0][j] - t[1][j]; other[j][e] = t[0][j]; }
+        }
+    }
+    float *xch = Bs;                           // [8 waves][32][64]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xch[(wave * 32 + j * 16 + e) * 64 + lane] = other[j][e];
+    __syncthreads();
+    const float *got = xch + ((wave ^ 4) * 32) * 64 + lane;
+
+    // ---- epilogue: output row i = wp of the wave's tiles, both columns ------------------------------
     const int co = co0 + wb * 32 + l31;
     const float sc = scale ? scale[co] : 1.f;
     const float sh = shift ? shift[co] : 0.f;
@@ -228,31 +287,21 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int tile = wa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-        const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
-        float tmp[4][2];
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            const float m0 = acc[xi * 4][e], m1 = acc[xi * 4 + 1][e], m2 = acc[xi * 4 + 2][e], m3 = acc[xi * 4 + 3][e];
-            tmp[xi][0] = m0 + m1 + m2;
-            tmp[xi][1] = m1 - m2 - m3;
-        }
+        const int yy = y0 + 2 * (tile >> 3) + wp, ox = x0 + 2 * (tile & 7);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float yv[2] = {tmp[0][j] + tmp[1][j] + tmp[2][j], tmp[1][j] - tmp[2][j] - tmp[3][j]};
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int yy = oy + i, xx = ox + j;
-                if (yy < H && xx < W) {
-                    const size_t o = ((size_t)yy * W + xx) * Cout + co;
-                    float v = yv[i] * sc + sh;
-                    v = v > 0.f ? v : v * slope;
-                    if (Gn) v = Gn[o] > 0.f ? v : v * gslope;
-                    Yn[o] = v * oscale;
-                }
+            const int xx = ox + j;
+            if (yy < H && xx < W) {
+                const size_t o = ((size_t)yy * W + xx) * Cout + co;
+                float v = (mine[j][e] + got[(j * 16 + e) * 64]) * sc + sh;
+                v = v > 0.f ? v : v * slope;
+                if (Gn) v = Gn[o] > 0.f ? v : v * gslope;
+                Yn[o] = v * oscale;
             }
         }
     }
 }
+
 
 // U[pos][Cin/8][2][Cout][4] = G g G^T of every (ci, co) filter; flip = the data-gradient filter
 // (taps mirrored; the caller swaps the channel strides)

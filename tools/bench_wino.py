@@ -68,6 +68,7 @@ def backbone_layers():
     own Winograd/MFMA launch vs library convolution + fused frozen-BN pass, forward and fwd+bwd."""
     from datr_amd import wino
     from datr_amd.fused import frozen_bn_act
+    wino.OWN_BACKBONE_3X3_MAX_CH = 1 << 20          # time every width, whatever the product routes
     dev = torch.device("cuda:0")
     for c, h, w_, n_blocks, train in ((64, 200, 334, 3, False), (128, 100, 167, 3, True), (256, 50, 84, 5, True),
                                       (512, 25, 42, 2, True)):
