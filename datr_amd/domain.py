@@ -77,11 +77,15 @@ class _DImgPyramid(torch.autograd.Function):
         conv_bwd = torch.ops.aten.convolution_backward
 
         def wgrad(dzs, ins, w):
-            """sum over levels of (dW, db) -- the library's weight-gradient convolution"""
+            """sum over levels of (dW, db): the library's weight-gradient convolution; the bias
+            gradient is the column sum of dz viewed [pixels, C] (NHWC), a deterministic two-stage own
+            kernel (csrc/ffn.hip) instead of ATen's 64-workgroup reduction"""
+            from .fused import column_sums
             dw = db = None
             for dz, a in zip(dzs, ins):
-                _, gw, gb = conv_bwd(dz, a, w, [w.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                     [False, True, True])
+                _, gw, _ = conv_bwd(dz, a, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                    [False, True, False])
+                gb = column_sums(dz.permute(0, 2, 3, 1).reshape(-1, dz.shape[1]))
                 dw = gw if dw is None else dw.add_(gw)
                 db = gb if db is None else db.add_(gb)
             return dw, db
