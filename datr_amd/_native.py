@@ -55,6 +55,9 @@ _SIGNATURES = {
     "datr_conv3x3_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
                                       ctypes.c_float, _vp, _vp],
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "datr_groupnorm_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _vp,
+                                        _vp, _vp],
+    "datr_groupnorm_nhwc_backward_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "datr_wino_weights_f32": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
     "datr_conv3x3_wino_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, _vp],
@@ -92,6 +95,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_add_layernorm_partial_floats.argtypes = [_i64]
     lib.datr_relu_bwd_bias_partial_rows.restype = ctypes.c_int64
     lib.datr_relu_bwd_bias_partial_rows.argtypes = [_i64]
+    lib.datr_groupnorm_partial_floats.restype = ctypes.c_int64
+    lib.datr_groupnorm_partial_floats.argtypes = [_i64, _i64, _i64, _i64]
     lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64
     lib.datr_wgrad_k256_scratch_floats.argtypes = []
     for name, argtypes in _SIGNATURES.items():

@@ -30,6 +30,7 @@ from . import boxes as box_ops
 from .backbone import build_backbone
 from .criterion import SetCriterion
 from .denoising import dn_post_process, prepare_for_cdn
+from .fused import GroupNormNHWC
 from .domain import (FCDiscriminator_img, decompose_features, get_prototype_class_wise,
                      grad_reverse)
 from .matcher import build_matcher
@@ -97,18 +98,18 @@ class DINO(nn.Module):
             projs = []
             for in_channels in backbone.num_channels:
                 projs.append(nn.Sequential(nn.Conv2d(in_channels, hidden_dim, kernel_size=1),
-                                           nn.GroupNorm(32, hidden_dim)))
+                                           GroupNormNHWC(32, hidden_dim)))
             for _ in range(num_feature_levels - len(backbone.num_channels)):
                 projs.append(nn.Sequential(
                     nn.Conv2d(in_channels, hidden_dim, kernel_size=3, stride=2, padding=1),
-                    nn.GroupNorm(32, hidden_dim)))
+                    GroupNormNHWC(32, hidden_dim)))
                 in_channels = hidden_dim
             self.input_proj = nn.ModuleList(projs)
         else:
             assert two_stage_type == "no", "two_stage_type should be no if num_feature_levels=1 !!!"
             self.input_proj = nn.ModuleList([nn.Sequential(
                 nn.Conv2d(backbone.num_channels[-1], hidden_dim, kernel_size=1),
-                nn.GroupNorm(32, hidden_dim))])
+                GroupNormNHWC(32, hidden_dim))])
 
         self.backbone = backbone
         self.aux_loss = aux_loss

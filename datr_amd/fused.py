@@ -66,6 +66,63 @@ def frozen_bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
     return torch.relu(y) if relu else y
 
 
+class _GroupNormNHWC(Function):
+    """F.group_norm on a channels_last [N, C, H, W] tensor without leaving that layout
+    (csrc/groupnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        N, C, H, W = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        mean = torch.empty(N, groups, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        part = torch.empty(int(_native.lib.datr_groupnorm_partial_floats(N, H * W, C, groups)), device=x.device,
+                           dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _native.lib.datr_groupnorm_nhwc_forward_f32(
+                x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, H * W, C, groups, eps, y.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), _native.current_stream_ptr(x.device))
+        _native.check(rc, "groupnorm_nhwc_forward")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        part = torch.empty(int(_native.lib.datr_groupnorm_partial_floats(N, H * W, C, ctx.groups)),
+                           device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _native.lib.datr_groupnorm_nhwc_backward_f32(
+                dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, H * W, C,
+                ctx.groups, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), part.data_ptr(),
+                _native.current_stream_ptr(x.device))
+        _native.check(rc, "groupnorm_nhwc_backward")
+        return dx, dgamma, dbeta, None, None
+
+
+class GroupNormNHWC(torch.nn.GroupNorm):
+    """nn.GroupNorm (same parameters, same state_dict names) whose device float32 channels_last
+    inputs stay channels_last: one own kernel pair each way instead of ATen's transpose to NCHW and
+    back (the input_proj norm of dino.py:111-126 between the NHWC backbone and the [N, HW, C] token
+    layout of the transformer).  Other inputs take nn.GroupNorm's path."""
+
+    def forward(self, x):
+        C = self.num_channels
+        cpg = C // self.num_groups
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.affine
+                and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+                and C % 4 == 0 and cpg % 4 == 0 and 256 % (C // 4) == 0 and C <= 1024
+                and not torch.is_autocast_enabled()):
+            return _GroupNormNHWC.apply(x, self.weight, self.bias, self.num_groups, self.eps)
+        return super().forward(x)
+
+
 def conv3x3_lrelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None,
                   slope: float = 1.0, out_scale: float = 1.0) -> torch.Tensor:
     """out_scale * leaky_relu(conv2d(x, weight, bias, stride 1, padding 1), slope) as ONE

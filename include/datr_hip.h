@@ -200,6 +200,21 @@ int datr_conv3x3_wino_nhwc_f32(const datr_wino_level *levels, int64_t nlevels, i
                                float slope, float gate_slope, float out_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GroupNorm on NHWC tensors (csrc/groupnorm.hip): `nn.GroupNorm(32, 256)` behind every input_proj
+ * convolution (/root/reference/models/dino/dino.py:111-126), kept in the backbone's NHWC layout
+ * (ATen transposes to NCHW and back).  x, y, dy, dx: [N, HW, C]; gamma, beta, dgamma, dbeta: [C];
+ * mean, rstd: [N, G] (written by the forward, read by the backward).  C % 4 == 0, (C / G) % 4 == 0,
+ * 256 % (C / 4) == 0, C <= 1024.  `partial`: datr_groupnorm_partial_floats(N, HW, C, G) floats of
+ * scratch; all sums are re-reduced in a fixed order (deterministic, no atomics). */
+int64_t datr_groupnorm_partial_floats(int64_t N, int64_t HW, int64_t C, int64_t G);
+int datr_groupnorm_nhwc_forward_f32(const float *x, const float *gamma, const float *beta, int64_t N,
+                                    int64_t HW, int64_t C, int64_t G, float eps, float *y, float *mean,
+                                    float *rstd, float *partial, void *stream);
+int datr_groupnorm_nhwc_backward_f32(const float *dy, const float *x, const float *mean, const float *rstd,
+                                     const float *gamma, int64_t N, int64_t HW, int64_t C, int64_t G,
+                                     float *dx, float *dgamma, float *dbeta, float *partial, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * FFN backward, the non-GEMM pass: given h = relu(linear1(x)) saved by the forward and
  * dh = d loss / d h, computes IN PLACE dh <- dh * (h > 0) and db[c] = sum_r dh[r, c]
  * (the bias gradient of linear1) in one pass over HBM

@@ -96,12 +96,15 @@ def force_reference_selection(model, golden, device):
     model.transformer.select_queries = forced
 
 
-def run_training_step(model, criterion, device, golden):
-    """One training forward + criterion + backward with the golden's CDN noise injected."""
+def run_training_step(model, criterion, device, golden, channels_last=False):
+    """One training forward + criterion + backward with the golden's CDN noise injected.
+    channels_last: the images (and whatever the caller did to the model) in NHWC -- bench.py's layout."""
     import synth
     from datr_amd.nested import nested_tensor_from_tensor_list
     imgs, targets = synth.synth_batch()
     samples = nested_tensor_from_tensor_list([i.to(device) for i in imgs])
+    if channels_last:
+        samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
     targets = [{k: v.to(device) for k, v in tg.items()} for tg in targets]
     model.train()
     criterion.train()

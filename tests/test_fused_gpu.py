@@ -312,6 +312,37 @@ def test_decoder_self_attention_matches_nn_multihead_attention(L):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 25, 42), (3, 256, 13, 21), (1, 256, 1, 3), (2, 64, 40, 52)])
+def test_groupnorm_nhwc_matches_float64_group_norm(shape):
+    """csrc/groupnorm.hip behind fused.GroupNormNHWC against F.group_norm in float64 (output, input
+    gradient, gamma / beta gradients) on inputs with a large common offset (mean >> std, the case the
+    shifted sums exist for); output and gradient stay channels_last; NCHW inputs take nn.GroupNorm."""
+    from datr_amd.fused import GroupNormNHWC
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(shape))
+    N, C, H, W = shape
+    gn = GroupNormNHWC(32 if C % 128 == 0 else 16, C).to(dev)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.normal_(0, 0.3)
+    x = (torch.randn(shape, device=dev) * 0.7 + 11.0).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    y = gn(x)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    gx, gw, gb = torch.autograd.grad(y, (x, gn.weight, gn.bias), go)
+    assert gx.is_contiguous(memory_format=torch.channels_last)
+    xd = x.detach().double().contiguous().requires_grad_(True)
+    wd, bd = gn.weight.detach().double().requires_grad_(True), gn.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.group_norm(xd, gn.num_groups, wd, bd, gn.eps)
+    rx, rw, rb = torch.autograd.grad(ref, (xd, wd, bd), go.double())
+    torch.testing.assert_close(y.double(), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gx.double(), rx, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gw.double(), rw, rtol=1e-4, atol=1e-4 * max(1.0, float(rw.abs().max())))
+    torch.testing.assert_close(gb.double(), rb, rtol=1e-4, atol=1e-4 * max(1.0, float(rb.abs().max())))
+    # an NCHW input is nn.GroupNorm's business (and gives an NCHW output)
+    assert gn(x.detach().contiguous()).is_contiguous()
+
+
 @pytest.mark.parametrize("L,masked", [(64, False), (300, True), (301, True), (1100, True), (1100, False)])
 def test_attention_d32_forward_and_backward_match_float64_math(L, masked):
     """csrc/mha_fwd.hip + csrc/mha_bwd.hip against softmax(q k^T / sqrt(32) + mask) v written out in

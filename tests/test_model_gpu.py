@@ -76,6 +76,33 @@ def test_step_with_reference_selection_matches_elementwise():
     assert d < 2e-4, float(d)
 
 
+def test_nhwc_step_with_reference_selection_matches_elementwise(monkeypatch):
+    """The same element-wise comparison in the layout bench.py trains in: backbone and images in
+    torch.channels_last, which routes conv2 + frozen BN + ReLU of the narrow bottlenecks through the
+    Winograd/MFMA kernel (every width here: the routing cap is lifted), the input_proj norms through
+    the NHWC GroupNorm kernels and the discriminator through its Winograd path without any layout
+    copy -- against the golden step of the reference."""
+    from datr_amd import domain, fused, wino
+    dev = torch.device("cuda:0")
+    g = load_npz("model_step.npz")
+    _, model, criterion, _ = build_model("cuda:0")
+    model.backbone.to(memory_format=torch.channels_last)
+    monkeypatch.setattr(wino, "OWN_BACKBONE_3X3_MAX_CH", 1 << 20)
+    calls = {"wino": 0, "gn": 0}
+    real_conv, real_gn = wino.wino_conv3x3, fused._GroupNormNHWC.apply
+    monkeypatch.setattr(wino, "wino_conv3x3", lambda *a, **k: (calls.__setitem__("wino", calls["wino"] + 1),
+                                                              real_conv(*a, **k))[1])
+    monkeypatch.setattr(domain, "wino_conv3x3", wino.wino_conv3x3)
+    monkeypatch.setattr(fused._GroupNormNHWC, "apply", lambda *a: (calls.__setitem__("gn", calls["gn"] + 1),
+                                                                  real_gn(*a))[1])
+    force_reference_selection(model, g, dev)
+    out, loss_dict, indices_list, total = run_training_step(model, criterion, dev, g, channels_last=True)
+    # 13 backbone convs + 3 discriminator layers forward; 10 trainable convs + 3 layers backward
+    assert calls["wino"] >= 13 + 3 + 10 + 3 and calls["gn"] == 4, calls
+    check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-3, loss_rtol=2e-3)
+    check_gradients(model, g, rtol=2e-2)
+
+
 def test_every_trainable_parameter_gets_a_finite_gradient(step):
     g, model, *_ = step
     norms = canonical_grad_norms(model)
