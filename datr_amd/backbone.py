@@ -23,6 +23,7 @@ from torch import nn
 
 from .fused import frozen_bn_act
 from .wino import conv3x3_bn_relu
+from . import pointwise
 from .nested import NestedTensor
 
 
@@ -86,19 +87,43 @@ class Bottleneck(nn.Module):
             out = self.relu(self.bn2(self.conv2(out)))
             return self.relu(self.bn3(self.conv3(out)) + identity)
         # frozen BN = per-channel affine: fold it with the ReLU / residual that follows into one
-        # pass over the activation (datr_amd.fused.frozen_bn_act)
+        # pass over the activation (datr_amd.fused.frozen_bn_act); in the NHWC layout the 1x1
+        # convolutions are GEMMs on the [pixels, channels] view (datr_amd.pointwise): conv1 + bn1 +
+        # ReLU is ONE GEMM with the scale folded into the weight and shift / ReLU in the epilogue
+        nhwc = (pointwise.GEMM_1X1 and x.is_cuda and x.dtype == torch.float32
+                and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
+        folded = getattr(self, "_folded", None) if nhwc else None
+        ds_conv = None if self.downsample is None else self.downsample[0]
         if self.downsample is None:
             identity = x
         else:
-            identity = frozen_bn_act(self.downsample[0](x), *self.downsample[1].scale_shift(),
-                                     relu=False)
-        out = frozen_bn_act(self.conv1(x), *self.bn1.scale_shift(), relu=True)
+            identity = None
+            if nhwc and ds_conv.stride == (1, 1) and folded is not None and folded[1] is not None:
+                identity = pointwise.conv1x1(x, folded[1], self.downsample[1].scale_shift()[1])
+            if identity is None:
+                identity = frozen_bn_act(ds_conv(x), *self.downsample[1].scale_shift(), relu=False)
+        out = None
+        if nhwc and folded is not None:
+            out = pointwise.conv1x1(x, folded[0], self.bn1.scale_shift()[1], relu=True)
+        if out is None:
+            out = frozen_bn_act(self.conv1(x), *self.bn1.scale_shift(), relu=True)
         out2 = None
         if self.conv2.stride == (1, 1):
             # 3x3 / stride 1 + frozen BN + ReLU: one Winograd/MFMA launch (csrc/wino.hip)
             out2 = conv3x3_bn_relu(out, self.conv2.weight, *self.bn2.scale_shift())
         out = out2 if out2 is not None else frozen_bn_act(self.conv2(out), *self.bn2.scale_shift(), relu=True)
-        return frozen_bn_act(self.conv3(out), *self.bn3.scale_shift(), residual=identity, relu=True)
+        y3 = pointwise.conv1x1(out, self.conv3.weight) if nhwc else None
+        if y3 is None:
+            y3 = self.conv3(out)
+        return frozen_bn_act(y3, *self.bn3.scale_shift(), residual=identity, relu=True)
+
+    def fold_pairs(self):
+        """(weight, frozen scale) of the 1x1 convolutions whose batch norm is folded into the GEMM:
+        conv1 and, when it has stride 1, the downsample convolution."""
+        pairs = [(self.conv1.weight, self.bn1.scale_shift()[0])]
+        if self.downsample is not None and self.downsample[0].stride == (1, 1):
+            pairs.append((self.downsample[0].weight, self.downsample[1].scale_shift()[0]))
+        return pairs
 
 
 class ResNet50Body(nn.Module):
@@ -150,7 +175,39 @@ class _StageOutputs(nn.ModuleDict):
         super().__init__(kept)
         self.return_layers = dict(return_layers)
 
+    def _fold_bottlenecks(self, x):
+        """Frozen-BN scales folded into the weights of every bottleneck's conv1 (and stride-1
+        downsample convolution) for this forward pass -- ONE multi-tensor multiply for the whole
+        trunk (datr_amd.pointwise.fold_frozen_bn); blocks read their share from `_folded`."""
+        blocks = [m for m in self.modules() if isinstance(m, Bottleneck)]
+        live = (pointwise.GEMM_1X1 and x.is_cuda and x.dtype == torch.float32
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and all(isinstance(b.bn1, FrozenBatchNorm2d) for b in blocks))
+        if not live:
+            for b in blocks:
+                b._folded = None
+            return
+        pairs, owner = [], []
+        for b in blocks:
+            for k, pr in enumerate(b.fold_pairs()):
+                pairs.append(pr)
+                owner.append((b, k))
+        folded = pointwise.fold_frozen_bn(pairs)
+        for b in blocks:
+            b._folded = [None, None]
+        for (b, k), f in zip(owner, folded):
+            b._folded[k] = f
+
     def forward(self, x):
+        self._fold_bottlenecks(x)
+        try:
+            return self._run(x)
+        finally:                               # graph tensors must not outlive the pass as module
+            for m in self.modules():           # attributes (copy.deepcopy of the model: EMA teacher)
+                if isinstance(m, Bottleneck):
+                    m._folded = None
+
+    def _run(self, x):
         out = OrderedDict()
         items = list(self.items())
         i = 0

@@ -172,6 +172,17 @@ class DINO(nn.Module):
             classes = torch.stack([h(x) for h, x in zip(self.class_embed, hs)])
         return classes, coords
 
+    def _input_proj(self, lvl, src):
+        """input_proj[lvl](src) (dino.py:111-126: 1x1 conv + GroupNorm); a channels_last device
+        input takes the convolution as a GEMM with the bias in its epilogue (datr_amd.pointwise)."""
+        from . import pointwise
+        conv, norm = self.input_proj[lvl][0], self.input_proj[lvl][1]
+        if conv.kernel_size == (1, 1) and conv.stride == (1, 1) and len(self.input_proj[lvl]) == 2:
+            y = pointwise.conv1x1(src, conv.weight, conv.bias)
+            if y is not None:
+                return norm(y)
+        return self.input_proj[lvl](src)
+
     def side_stream_parameters(self):
         """Parameters whose gradients are produced on the side stream (the image-level
         discriminator when OVERLAP_D_IMG): datr_amd.dist.GradAllReducer buckets them apart."""
@@ -193,7 +204,7 @@ class DINO(nn.Module):
         for lvl, feat in enumerate(features):
             src, mask = feat.decompose()
             assert mask is not None
-            srcs.append(self.input_proj[lvl](src))
+            srcs.append(self._input_proj(lvl, src))
             masks.append(mask)
         for lvl in range(len(srcs), self.num_feature_levels):
             src = self.input_proj[lvl](features[-1].tensors if lvl == len(features) else srcs[-1])

@@ -1,5 +1,5 @@
 """Re-create gemm_mi355x.csv on a MI355X:  python -m datr_amd.tuning.retune
-Runs two warm-up steps of bench.py's training step with TunableOp tuning enabled and writes
+Runs two steps of the training step bench.py times (datr_amd.training.Stepper) with TunableOp tuning enabled and writes
 the selections next to this file."""
 import os
 import sys
@@ -11,29 +11,25 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    import bench
     from datr_amd import tuning
+    from datr_amd.training import Stepper, synthetic_batch
     t = torch.cuda.tunable
     t.enable(True)
     t.tuning_enable(True)
     t.set_max_tuning_duration(60)
     t.set_filename("/tmp/datr_tunableop_scratch.csv", insert_device_ordinal=False)
-
-    class A:
-        flat_grads = False
-        tuned_gemm = False
-        channels_last = True
     dev = torch.device("cuda:0")
-    tr = bench.Trainer(A, dev, distributed=False)
+    tr = Stepper(dev, tuned_gemm=False, channels_last=True)
+    tuning.enable_miopen_db()
     for size, b, gt in (((800, 1333), 2, 10), ((640, 640), 1, 5)):
-        samples, targets = bench.synthetic_batch(b, size[0], size[1], gt, dev, seed=1)
+        samples, targets = synthetic_batch(b, size[0], size[1], gt, dev, seed=1)
         for _ in range(2):
             tr.step(samples, targets)
         # the eval-mode forward of the teacher / the evaluation loop (target half only: other M)
         tr.model.eval()
         with torch.no_grad():
             half = samples.tensors.shape[0] // 2
-            tr.model(samples.tensors[half:].contiguous())
+            tr.model(samples.tensors[half:].contiguous(memory_format=torch.channels_last))
         tr.model.train()
     torch.cuda.synchronize()
     results = {(op, params): (solution, ms) for op, params, solution, ms in t.get_results()}

@@ -140,3 +140,48 @@ def test_backbone_bottleneck_routes_conv2_through_the_own_kernel(monkeypatch):
         monkeypatch.setattr(wino, "OWN_BACKBONE_3X3", False)
         y_lib = blk(x)
     torch.testing.assert_close(y_own, y_lib, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,hw,relu,bias", [(64, 256, (40, 52), False, False), (256, 64, (25, 42), True, True),
+                                                   (512, 256, (13, 21), False, True), (2048, 512, (7, 11), True, True)])
+def test_conv1x1_as_gemm_matches_float64_convolution(cin, cout, hw, relu, bias, monkeypatch):
+    """datr_amd.pointwise.conv1x1 (1x1 convolution of a channels_last tensor as a GEMM on the
+    [pixels, C] view, bias / ReLU in the epilogue) against F.conv2d in float64: output, input, weight
+    and bias gradients -- with the weight gradient once through the GEMM and once through the library
+    convolution (the routing threshold is moved across the test size)."""
+    from datr_amd import pointwise
+    dev = torch.device("cuda:0")
+    torch.manual_seed(cin + cout)
+    x = torch.randn(2, cin, *hw, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, device=dev).requires_grad_(True) if bias else None
+    go = torch.randn(2, cout, *hw, device=dev).contiguous(memory_format=torch.channels_last)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True) if bias else None
+    ref = F.conv2d(xd, wd, bd)
+    ref = ref.relu() if relu else ref
+    rg = torch.autograd.grad(ref, [xd, wd] + ([bd] if bias else []), go.double())
+    for max_px in (0, 1 << 30):
+        monkeypatch.setattr(pointwise, "WGRAD_GEMM_MAX_PIXELS", max_px)
+        y = pointwise.conv1x1(x, w, b, relu=relu)
+        assert y is not None and y.is_contiguous(memory_format=torch.channels_last)
+        g = torch.autograd.grad(y, [x, w] + ([b] if bias else []), go)
+        torch.testing.assert_close(y.double(), ref, rtol=1e-4, atol=1e-4)
+        for a, r in zip(g, rg):
+            torch.testing.assert_close(a.double(), r, rtol=1e-4, atol=1e-4 * max(1.0, float(r.abs().max())))
+    assert pointwise.conv1x1(x.detach().contiguous(), w, b, relu=relu) is None      # NCHW: library path
+
+
+def test_fold_frozen_bn_folds_and_backpropagates():
+    from datr_amd.pointwise import fold_frozen_bn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ws = [torch.randn(c, 8, 1, 1, device=dev, requires_grad=(i != 1)) for i, c in enumerate((4, 8, 12))]
+    ss = [torch.rand(c, device=dev) + 0.5 for c in (4, 8, 12)]
+    f = fold_frozen_bn(list(zip(ws, ss)))
+    for w, s, o in zip(ws, ss, f):
+        torch.testing.assert_close(o, w.detach().reshape(w.shape[0], -1) * s[:, None])
+    (f[0].sum() * 2 + f[2].sum()).backward()
+    torch.testing.assert_close(ws[0].grad, (2 * ss[0]).view(-1, 1, 1, 1).expand_as(ws[0]))
+    torch.testing.assert_close(ws[2].grad, ss[2].view(-1, 1, 1, 1).expand_as(ws[2]))
+    assert ws[1].grad is None and f[1] is fold_frozen_bn([(ws[1], ss[1])])[0]       # frozen: cached
