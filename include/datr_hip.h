@@ -215,6 +215,18 @@ int datr_groupnorm_nhwc_backward_f32(const float *dy, const float *x, const floa
                                      float *dx, float *dgamma, float *dbeta, float *partial, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Bilinear resize + optional horizontal flip of a uint8 [H, W, 3] image, bit-exact with Pillow's
+ * `Image.resize(size, BILINEAR)` -- what `F.resize` / `F.hflip` do in the reference's
+ * RandomResize / RandomHorizontalFlip (/root/reference/datasets/da_transforms.py:62-140; Pillow is
+ * un-vendored, its 8-bit separable resampler is restated).  xbounds / ybounds: {first source index,
+ * count} per output column / row; xk / yk: ksx / ksy 22-bit fixed-point weights per output column /
+ * row (host-computed as Pillow computes them, datr_amd/input_pipeline.py::pillow_coeffs).  tmp:
+ * H * ow * 3 bytes of scratch.  flip mirrors the SOURCE reads (flip first, then resize). */
+int datr_resize_bilinear_u8(const uint8_t *src, int64_t H, int64_t W, int flip, const int32_t *xbounds,
+                            const int32_t *xk, int64_t ksx, const int32_t *ybounds, const int32_t *yk,
+                            int64_t ksy, int64_t oh, int64_t ow, uint8_t *tmp, uint8_t *dst, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * FFN backward, the non-GEMM pass: given h = relu(linear1(x)) saved by the forward and
  * dh = d loss / d h, computes IN PLACE dh <- dh * (h > 0) and db[c] = sum_r dh[r, c]
  * (the bias gradient of linear1) in one pass over HBM
