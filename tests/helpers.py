@@ -160,7 +160,14 @@ def check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol
     torch.testing.assert_close(float(total), float(g["total_loss"]), rtol=loss_rtol, atol=1e-3)
 
 
-def check_gradients(model, g, rtol=2e-2):
+def check_gradients(model, g, rtol=2e-2, outlier_fraction=0.0):
+    """Per-parameter gradient norms and a few full gradients against the golden step.
+    outlier_fraction > 0: bilinear sampling is piecewise linear in the sampling location, so its
+    gradient JUMPS where a location crosses a pixel boundary; a last-bit difference in a location
+    (other GEMM / convolution kernels upstream) can put one sample on the other side, which moves a
+    handful of elements of the encoder-side gradients by a few per cent (observed run to run:
+    tools/probes/nhwc_repro.py).  Then up to that fraction of a tensor's elements may miss the
+    element-wise tolerance, by no more than 15 % of the tensor's largest element."""
     norms = canonical_grad_norms(model)
     assert sorted(norms) == sorted(str(k) for k in g["grad_keys"])
     assert all(v is not None for v in norms.values()), "a trainable parameter got no gradient"
@@ -174,5 +181,11 @@ def check_gradients(model, g, rtol=2e-2):
             p = sd[key[6:]]
             mine = p.grad if p.grad.numel() < 5000 else p.grad.flatten()[:5000]
             scale = float(np.abs(g[key]).max()) + 1e-12
-            torch.testing.assert_close(mine.detach().float().cpu(), t(g[key]), rtol=2e-2,
-                                       atol=2e-3 * scale)
+            mine, want = mine.detach().float().cpu(), t(g[key])
+            if outlier_fraction > 0:
+                err = (mine - want).abs()
+                miss = err > 2e-2 * want.abs() + 2e-3 * scale
+                assert float(miss.float().mean()) <= outlier_fraction and float(err.max()) <= 0.15 * scale, \
+                    (key, float(miss.float().mean()), float(err.max()), scale)
+                continue
+            torch.testing.assert_close(mine, want, rtol=2e-2, atol=2e-3 * scale)

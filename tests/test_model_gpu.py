@@ -100,7 +100,7 @@ def test_nhwc_step_with_reference_selection_matches_elementwise(monkeypatch):
     # 13 backbone convs + 3 discriminator layers forward; 10 trainable convs + 3 layers backward
     assert calls["wino"] >= 13 + 3 + 10 + 3 and calls["gn"] == 4, calls
     check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-3, loss_rtol=2e-3)
-    check_gradients(model, g, rtol=2e-2)
+    check_gradients(model, g, rtol=3e-2, outlier_fraction=0.05)
 
 
 def test_every_trainable_parameter_gets_a_finite_gradient(step):
