@@ -649,12 +649,12 @@ int datr_msda_forward_tiled_f32(const float *value, const int64_t *shapes,
                                  stream);
 }
 
-int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
-                                 const int64_t *level_start, const int64_t *shapes_host,
-                                 const int64_t *level_start_host, const float *loc,
-                                 const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
-                                 int64_t L, int64_t Lq, int64_t P, float *grad_value,
-                                 float *grad_loc, float *grad_attn, void *stream) {
+static int backward_tiled_impl(const float *grad_out, const float *value, const int64_t *shapes,
+                               const int64_t *level_start, const int64_t *shapes_host,
+                               const int64_t *level_start_host, const float *loc,
+                               const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                               int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                               float *grad_loc, float *grad_attn, void *stream, bool allow_pyr) {
     // The tiled kernel needs the level geometry on the host (grid size, window maths); anything
     // it does not cover takes the row kernel.
     DatrTiledMeta meta;
@@ -676,7 +676,7 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
     // encoder calls: pyramid regions, grad_value by sorted scatter (msda_bwd_pyr.hip);
     // DATR_MSDA_PYR_BWD=0 keeps the query-tiled kernel (A/B measurements)
     static const bool pyr_bwd = !(getenv("DATR_MSDA_PYR_BWD") && atoi(getenv("DATR_MSDA_PYR_BWD")) == 0);
-    if (Lq == S && pyr_bwd) {
+    if (Lq == S && pyr_bwd && allow_pyr) {
         const int rc = datr_internal_msda_bwd_pyr_d32(grad_out, value, loc, attn, shapes_host,
                                                       level_start_host, N, S, M, D, L, Lq, P,
                                                       grad_value, grad_loc, grad_attn, stream);
@@ -684,6 +684,26 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
     }
     return datr_internal_msda_bwd_tiled_d32(grad_out, value, loc, attn, &meta, N, S, M, P,
                                             grad_value, grad_loc, grad_attn, stream);
+}
+
+int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                                 const int64_t *level_start, const int64_t *shapes_host,
+                                 const int64_t *level_start_host, const float *loc,
+                                 const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                 int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                 float *grad_loc, float *grad_attn, void *stream) {
+    return backward_tiled_impl(grad_out, value, shapes, level_start, shapes_host, level_start_host, loc, attn, N,
+                               S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, stream, true);
+}
+
+int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                                       const int64_t *level_start, const int64_t *shapes_host,
+                                       const int64_t *level_start_host, const float *loc,
+                                       const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                       int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                       float *grad_loc, float *grad_attn, void *stream) {
+    return backward_tiled_impl(grad_out, value, shapes, level_start, shapes_host, level_start_host, loc, attn, N,
+                               S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, stream, false);
 }
 
 int datr_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import math
 import warnings
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -86,8 +87,9 @@ def _host_meta(shapes: torch.Tensor, lsi: torch.Tensor):
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                           im2col_step: int):
-    """-> Tensor [N, Lq, M*D]  (same contract as MSDA.ms_deform_attn_forward)."""
+                           im2col_step: int, route: int = 0):
+    """-> Tensor [N, Lq, M*D]  (same contract as MSDA.ms_deform_attn_forward).
+    route (see OffsetMonitor): 0 = kernel by geometry; > 0 = no pyramid-region kernel."""
     for t, nme in ((value, "value"), (spatial_shapes, "spatial_shapes"),
                    (level_start_index, "level_start_index"), (sampling_loc, "sampling_loc"),
                    (attn_weight, "attn_weight")):
@@ -102,7 +104,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = _native.current_stream_ptr(value.device)
-        if sfx == "f32" and D == 32 and Lq == S and L == 4 and P == 4 and PYR_FORWARD:
+        if sfx == "f32" and D == 32 and Lq == S and L == 4 and P == 4 and PYR_FORWARD and route == 0:
             # encoder self-attention: pyramid-region forward, coarse-level windows staged in LDS
             sh_host, ls_host = _host_meta(shapes, lsi)
             rc = _native.lib.datr_msda_forward_tiled_f32(
@@ -118,8 +120,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                            grad_output, im2col_step: int):
-    """-> [grad_value, grad_sampling_loc, grad_attn_weight]."""
+                            grad_output, im2col_step: int, route: int = 0):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight].
+    route: 0 = kernel by geometry; 1 = no pyramid-region kernel; 2 = the row kernel."""
     for t, nme in ((value, "value"), (spatial_shapes, "spatial_shapes"),
                    (level_start_index, "level_start_index"), (sampling_loc, "sampling_loc"),
                    (attn_weight, "attn_weight"), (grad_output, "grad_output")):
@@ -132,10 +135,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
         stream = _native.current_stream_ptr(value.device)
-        if sfx == "f32" and D == 32 and Lq >= TILED_BACKWARD_MIN_LQ:
-            # query-tiled backward (LDS accumulation): needs the geometry on the host
+        if sfx == "f32" and D == 32 and Lq >= TILED_BACKWARD_MIN_LQ and route < 2:
+            # geometry-dispatched backward (pyramid regions / owner-computes / query tiles): needs
+            # the geometry on the host
             sh_host, ls_host = _host_meta(shapes, lsi)
-            rc = _native.lib.datr_msda_backward_tiled_f32(
+            entry = (_native.lib.datr_msda_backward_tiled_f32 if route == 0
+                     else _native.lib.datr_msda_backward_query_tiled_f32)
+            rc = entry(
                 grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
                 sh_host.ctypes.data, ls_host.ctypes.data, sampling_loc.data_ptr(),
                 attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
@@ -152,10 +158,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
 class MSDeformAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                attention_weights, im2col_step):
+                attention_weights, im2col_step, route=0):
         ctx.im2col_step = im2col_step
+        ctx.route = int(route)
+        kw = {"route": ctx.route} if ctx.route else {}
         output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                        sampling_locations, attention_weights, ctx.im2col_step)
+                                        sampling_locations, attention_weights, ctx.im2col_step, **kw)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return output
@@ -164,9 +172,10 @@ class MSDeformAttnFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
+        kw = {"route": ctx.route} if ctx.route else {}
         grad_value, grad_loc, grad_attn = ms_deform_attn_backward(
-            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step)
-        return grad_value, None, None, grad_loc, grad_attn, None
+            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step, **kw)
+        return grad_value, None, None, grad_loc, grad_attn, None, None
 
 
 def _is_power_of_2(n: int) -> bool:
@@ -252,6 +261,63 @@ def _inverse_wh(spatial_shapes: torch.Tensor, n_heads: int, n_points: int) -> to
     return hit[0]
 
 
+class OffsetMonitor:
+    """Watches how far an encoder layer's sampling offsets reach and routes its MSDA calls.
+
+    The pyramid-region kernels stage windows of footprint + 4.5 px and are the fastest choice while
+    nearly all samples stay inside (a DINO encoder: the ring initialisation reaches 4 px and training
+    moves the offsets by a few pixels); samples outside take a slow path, and with MANY outside the
+    other kernels win (N = 4 encoder call at 1333x800, forward / backward in us,
+    tools/bench_msda.py):   offsets ~ N(0, s px)    pyramid      row fwd / query-tiled bwd    row bwd
+                                 s = 1.5             180 /  994        239 / 1160               -
+                                 s = 2.5             223 / 1416        252 / 1362             4642
+                                 s = 4               327 / 2788        249 / 2462             4178
+                                 s = 6               373 / 7107        249 / 5191             3645
+                                 uniform             530 / 51238       272 / 11461            4668
+    Every `every`-th call the fraction f of (sub-sampled) samples whose offset exceeds the halo in
+    x or y is computed on the device and copied to pinned memory without synchronising; a later
+    call that finds the copy complete updates the route: f < 0.25 -> 0 (pyramid), f < 0.62 -> 1 (row
+    forward, query-tiled backward), else 2 (row kernels).  One step of lag, no host sync."""
+
+    HALO_PX = 4.5
+
+    def __init__(self, every: int = 50):
+        self.every, self.calls, self.route, self.fraction = every, 0, 0, 0.0
+        self._pending = None
+
+    @staticmethod
+    def route_for(fraction: float) -> int:
+        return 0 if fraction < 0.25 else (1 if fraction < 0.62 else 2)
+
+    def poll(self):
+        if self._pending is not None and self._pending[1].query():
+            self.fraction = float(self._pending[0][0])
+            self.route = self.route_for(self.fraction)
+            self._pending = None
+        return self.route
+
+    def observe(self, offsets_norm: torch.Tensor, inv_wh: torch.Tensor):
+        """offsets_norm [N, Lq, 256]: offsets in units of the level's width / height (x, y
+        interleaved); inv_wh [256] = 1 / (W_l or H_l) per column."""
+        self.calls += 1
+        if self._pending is not None or (self.calls - 1) % self.every:
+            return
+        with torch.no_grad():
+            stride = max(1, offsets_norm.shape[1] // 512)
+            px = offsets_norm.detach()[:, ::stride].abs() / inv_wh
+            far = (px > self.HALO_PX).view(*px.shape[:-1], -1, 2).any(-1)
+            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host.copy_(far.float().mean().view(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending = (host, ev)
+
+
+_MONITORS = weakref.WeakKeyDictionary()            # module -> OffsetMonitor (not part of the module:
+#                                                    events and pinned buffers do not deep-copy)
+ADAPTIVE_ROUTING = __import__("os").environ.get("DATR_MSDA_ADAPTIVE", "1") != "0"
+
+
 class MSDeformAttn(nn.Module):
     """Same constructor, parameter names (state_dict keys `sampling_offsets`,
     `attention_weights`, `value_proj`, `output_proj`), initialisation and forward signature as
@@ -323,8 +389,15 @@ class MSDeformAttn(nn.Module):
                     and reference_points.shape[-1] in (2, 4) \
                     and (fold_wh or reference_points.shape[-1] == 4) and value.dtype == torch.float32:
                 locations, weights = _Prologue.apply(both, reference_points.float())
+                route = 0
+                if fold_wh and ADAPTIVE_ROUTING and Len_q == Len_in:       # encoder self-attention
+                    mon = _MONITORS.get(self)
+                    if mon is None:
+                        mon = _MONITORS[self] = OffsetMonitor()
+                    route = mon.poll()
+                    mon.observe(both[..., :self.sampling_offsets.out_features], inv)
                 out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                                 locations, weights, self.im2col_step)
+                                                 locations, weights, self.im2col_step, route)
                 return self.output_proj(out)
             n_off = self.sampling_offsets.out_features
             off2, wts2 = _SplitLast.apply(both, n_off)

@@ -70,17 +70,21 @@ int datr_msda_backward_f32(const float *grad_out, const float *value, const int6
                            int64_t L, int64_t Lq, int64_t P,
                            float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
-/* Same contracts as datr_msda_forward_f32 / datr_msda_backward_f32, for callers that also hold HOST copies of `shapes`
- * and `level_start` (the reference builds both from python ints,
- * /root/reference/models/dino/deformable_transformer.py:267-290, so a binding has them for
- * free).  For D == 32 the query-tiled kernels work on 16 x 8 pixel tiles when Lq == S (the
- * queries are the pyramid's own pixels -- the encoder's self-attention).  The backward
- * accumulates grad_value in LDS (fixed point) and flushes each touched row once instead of one
- * global float atomic per contribution (also for other Lq, with tiles of 128 consecutive
- * queries): this is the product path.  The forward (P == 4, L <= 4) stages a window of value rows
- * per level in LDS and gathers from there; it is parity-green but measured slower than
- * datr_msda_forward_f32 on MI355X and is kept for A/B measurements only.  Every other shape
- * falls through to the plain entry points.  The host arrays are only read during the call. */
+/* Same contracts as datr_msda_forward_f32 / datr_msda_backward_f32, for callers that also hold HOST
+ * copies of `shapes` and `level_start` (the reference builds both from python ints,
+ * /root/reference/models/dino/deformable_transformer.py:267-290, so a binding has them for free):
+ * the library then picks the kernel by geometry -- this is the product path.  D == 32, L == P == 4,
+ * Lq == S (the encoder's self-attention: the queries are the pyramid's own pixels): the
+ * pyramid-region kernels (csrc/msda_fwd_pyr.hip: coarse-level windows gathered out of LDS;
+ * csrc/msda_bwd_pyr.hip: grad_value by sorted scatter).  Lq != S, Lq <= 4096 (the decoder's
+ * cross-attention): the owner-computes backward (csrc/msda_bwd_owner.hip, no atomics, no zero-fill).
+ * Other D == 32 shapes: the query-tiled backward (fixed-point LDS accumulation, each touched row
+ * flushed once).  Everything else falls through to the plain entry points.  Results never depend
+ * on the window heuristics; the host arrays are only read during the call.
+ * datr_msda_backward_query_tiled_f32 is the same dispatch WITHOUT the pyramid-region kernel: the
+ * pyramid kernels are tuned for offsets of a few pixels and degrade when many samples leave their
+ * windows, so a caller that watches the offset distribution (datr_amd/msda.py) routes wide
+ * distributions here (medium) or to datr_msda_backward_f32 (very wide). */
 int datr_msda_forward_tiled_f32(const float *value, const int64_t *shapes,
                                 const int64_t *level_start, const int64_t *shapes_host,
                                 const int64_t *level_start_host, const float *loc,
@@ -92,6 +96,12 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
                                  const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
                                  int64_t L, int64_t Lq, int64_t P, float *grad_value,
                                  float *grad_loc, float *grad_attn, void *stream);
+int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                                       const int64_t *level_start, const int64_t *shapes_host,
+                                       const int64_t *level_start_host, const float *loc,
+                                       const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                       int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                       float *grad_loc, float *grad_attn, void *stream);
 
 /* Double-precision twins (generic kernels; they exist so the reference's gradcheck-in-double
  * op test, /root/reference/models/dino/ops/test.py:63-86, can be restated). */

@@ -381,3 +381,58 @@ def test_owner_backward_for_decoder_queries(M, O, dev, mode, monkeypatch):
     torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
     keep = off_grid(loc, sh, eps=1e-4)
     torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
+
+
+def test_routes_agree_and_the_offset_monitor_switches_them():
+    """The three kernel routes of the encoder call (0: pyramid regions, 1: row forward + query-tiled
+    backward, 2: row kernels) compute the same op -- compared on offsets wide enough that a large
+    share of the samples leaves the pyramid windows -- and datr_amd.msda.OffsetMonitor moves an
+    encoder layer from route 0 to the others once it has seen such offsets (asynchronous read-back:
+    the switch happens on a later call, never through a host synchronisation inside the call)."""
+    from datr_amd import msda
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    shapes_l = [(40, 54), (20, 27), (10, 14), (5, 7)]
+    shapes = torch.tensor(shapes_l, dtype=torch.int64, device=dev)
+    lsi = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    S = int(shapes.prod(1).sum())
+    N, M, D, L, P = 2, 8, 32, 4, 4
+    value = torch.randn(N, S, M, D, device=dev)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h,
+                                                (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"), -1)
+                     .flip(-1).reshape(-1, 2) for h, w in shapes_l], 0)
+    wh = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32, device=dev).view(1, 1, 1, L, 1, 2)
+    loc = (ref.view(1, S, 1, 1, 1, 2) + torch.randn(N, S, M, L, P, 2, device=dev) * 5.0 / wh).contiguous()
+    attn = torch.softmax(torch.randn(N, S, M, L * P, device=dev), -1).view(N, S, M, L, P)
+    go = torch.randn(N, S, M * D, device=dev)
+    res = []
+    for route in (0, 1, 2):
+        v, l_, a = (x.clone().requires_grad_(True) for x in (value, loc, attn))
+        out = msda.MSDeformAttnFunction.apply(v, shapes, lsi, l_, a, 64, route)
+        res.append([out.detach()] + list(torch.autograd.grad(out, (v, l_, a), go)))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())))
+
+    assert [msda.OffsetMonitor.route_for(f) for f in (0.0, 0.2, 0.3, 0.6, 0.7, 1.0)] == [0, 0, 1, 1, 2, 2]
+    mod = msda.MSDeformAttn(256, 4, 8, 4).to(dev)
+    query = torch.randn(N, S, 256, device=dev)
+    src = torch.randn(N, S, 256, device=dev)
+    refpts = ref.view(1, S, 1, 2).expand(N, S, L, 2).contiguous()
+
+    def call():
+        return mod(query, refpts, src, shapes, lsi)
+    y0 = call()
+    torch.cuda.synchronize()
+    call()
+    mon = msda._MONITORS[mod]
+    assert mon.route == 0 and mon.fraction == 0.0                 # ring initialisation: nothing beyond 4 px
+    with torch.no_grad():
+        mod.sampling_offsets.bias.mul_(2.5)                       # up to 10 px: most points leave the halo
+    mon.calls = 0                                                 # next call probes again
+    y1 = call()
+    torch.cuda.synchronize()
+    y2 = call()                                                   # finds the read-back complete
+    assert mon.fraction > 0.5 and mon.route == msda.OffsetMonitor.route_for(mon.fraction) and mon.route > 0
+    torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-4)      # route 0 vs the new route: same values
+    assert y0.shape == y1.shape
