@@ -265,6 +265,16 @@ def add_layer_norm(x: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm)
     return norm(x + res)
 
 
+def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
+    """norm(x) for the two LayerNorms of the path that follow no residual add (`enc_output_norm`
+    over all encoder tokens, deformable_transformer.py:335-336, and the decoder's output norm,
+    :725) through the same one-pass kernels (csrc/layernorm.hip with a null residual)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and norm.elementwise_affine \
+            and norm.bias is not None and tuple(norm.normalized_shape) == (256,):
+        return _AddLayerNorm.apply(x, None, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
 def topk_rows(scores: torch.Tensor, k: int):
     """(values, indices) of the k largest entries of every row of `scores` [rows, n], sorted by
     descending value, EQUAL values by ascending index (csrc/topk.hip): one total order, so the

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .fused import FastLinear
-from .fused import attention_d32
+from .fused import attention_d32, layer_norm
 from .fused import linear as fused_linear
 from .msda import MSDeformAttn
 from .nested import inverse_sigmoid
@@ -406,7 +406,7 @@ class TransformerDecoder(nn.Module):
                            + inverse_sigmoid(reference_points)).sigmoid()
                 reference_points = new_ref.detach()
                 ref_points.append(reference_points if self.use_detached_boxes_dec_out else new_ref)
-            intermediate.append(self.norm(output))
+            intermediate.append(layer_norm(output, self.norm))
         return [[x.transpose(0, 1) for x in intermediate],
                 [r.transpose(0, 1) for r in ref_points]]
 
@@ -592,7 +592,7 @@ class DeformableTransformer(nn.Module):
             input_hw = self.two_stage_wh_embedding.weight[0] if self.two_stage_learn_wh else None
             output_memory, output_proposals = gen_encoder_output_proposals(
                 memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding)
-            output_memory = self.enc_output_norm(self.enc_output(output_memory))
+            output_memory = layer_norm(self.enc_output(output_memory), self.enc_output_norm)
             enc_class = self.enc_out_class_embed(output_memory)
             enc_coord = self.enc_out_bbox_embed(output_memory) + output_proposals   # logits
             topk_idx = self.select_queries(enc_class.max(-1)[0])

@@ -16,7 +16,9 @@ def main():
     t = torch.cuda.tunable
     t.enable(True)
     t.tuning_enable(True)
-    t.set_max_tuning_duration(60)
+    t.set_max_tuning_duration(int(os.environ.get("DATR_TUNE_MS", "60")))
+    if os.environ.get("DATR_TUNE_ITERS"):
+        t.set_max_tuning_iterations(int(os.environ["DATR_TUNE_ITERS"]))
     t.set_filename("/tmp/datr_tunableop_scratch.csv", insert_device_ordinal=False)
     dev = torch.device("cuda:0")
     tr = Stepper(dev, tuned_gemm=False, channels_last=True)

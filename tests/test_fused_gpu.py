@@ -422,3 +422,23 @@ def test_fused_sampling_prologue_matches_torch_ops(ref_dim, Lq):
             msda.FUSED_PROLOGUE = True
     for a, b in zip(*res):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+
+
+def test_plain_layer_norm_through_the_fused_kernel_matches_autograd():
+    """fused.layer_norm (csrc/layernorm.hip with a null residual: enc_output_norm, decoder norm)
+    against nn.LayerNorm under autograd."""
+    from datr_amd.fused import layer_norm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    ln = torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.2)
+    x = (torch.randn(3, 701, 256, device=dev) * 2 + 0.5).requires_grad_(True)
+    go = torch.randn_like(x)
+    got = torch.autograd.grad(layer_norm(x, ln), (x, ln.weight, ln.bias), go)
+    y_ref = ln(x)
+    ref = torch.autograd.grad(y_ref, (x, ln.weight, ln.bias), go)
+    torch.testing.assert_close(layer_norm(x, ln), y_ref, rtol=1e-5, atol=1e-5)
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())))
