@@ -407,6 +407,13 @@ def main():
             # GPU time of the op at the CPU leg's shape (N=2): the merged N=4 launch / 2
             gpu_us = roof["mean_us"] * 2 / timer.shape[0] if roof else None
             line["cpu_baseline"] = cpu_baseline(gpu_us)
+        # RCCL writes its version banner through C stdio, which sits in a buffer when stdout is a pipe
+        # and would come out AFTER this line at exit: push it out first, the JSON line stays the last one
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
