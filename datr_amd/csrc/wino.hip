@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "datr_hip.h"
 
@@ -56,7 +57,6 @@ constexpr int kLdsBytes = (2 * kPatchF + 2 * kVF + 2 * kBF) * 4;   // 148.7 KB: 
 struct WinoLevel { const float *x; float *y; const float *gate; int H, W, tbx, tby, first; };
 struct WinoArgs { WinoLevel lv[DATR_WINO_MAX_LEVELS]; int nlevels, Cin, Cout; float slope, gate_slope, out_scale; };
 
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const float *__restrict__ U,
@@ -114,18 +114,27 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
     };
     // raw patch of chunk c: 324 pixels x 2 float4 (648 <= 2 x 512), zero outside the image;
     // register-staged so that the loads of chunk c + 3 are in flight while chunk c is multiplied
+    // The pixel of each of this thread's two float4 does not change from chunk to chunk: its byte
+    // offset is worked out once (0x80000000 outside the image / past the patch: a raw buffer load
+    // returns zeros there, no select), the chunk only moves the scalar offset.
     float4 pf[2];
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(Xn), 0, H * W * Cin * 4, 0x00020000);
+    unsigned poff[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int f = tid + u * kThreads;
+        const int pix = f >> 1, h = f & 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+        const bool in = f < 2 * PPIX && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        poff[u] = in ? (unsigned)(((yy * W + xx) * Cin + h * 4) * 4) : 0x80000000u;
+    }
     auto fetch_patch = [&](int c) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int f = tid + u * kThreads;
-            const int pix = f >> 1, h = f & 1;
-            const int py = pix / PW, px = pix - py * PW;
-            const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < 2 * PPIX && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                v = *reinterpret_cast<const float4 *>(Xn + ((size_t)yy * W + xx) * Cin + c * CK + h * 4);
-            pf[u] = v;
+            const auto r_ = __builtin_amdgcn_raw_buffer_load_b128(xsrc, poff[u], c * CK * 4, 0);
+            pf[u] = __builtin_bit_cast(float4, r_);
         }
     };
     auto store_patch = [&](float *dst) {
@@ -138,37 +147,39 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
     };
 
     // transform unit of this thread: (tile, channel half, pair of transform rows, pair of transform
-    // columns); everything but the tile is wave-uniform.  Row pair q: rows 0,1 from patch rows 0-2,
-    // rows 2,3 from patch rows 1-3; column pair likewise from patch columns 0-2 / 1-3.
+    // columns); everything but the tile is wave-uniform.  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:
+    // rows {0, 1} are (d0 - d2, d1 + d2), rows {2, -3} are (d2 - d1, d3 - d1) -- with the LAST row /
+    // column negated (the filter transform carries the same sign, wino_weights) both pairs are
+    // (A - B, C + s B) over three patch rows (A, B, C) = (0, 2, 1), s = +1 or (2, 1, 3), s = -1: the
+    // rows are LOADED in that order, so no register selects and no branches in the loop.
     const int t_tile = tid & 63;
     const int t_half = wave & 1, t_rp = (wave >> 1) & 1, t_cp = wave >> 2;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    const int p_off = (t_half * PPIX + (2 * t_ty + t_rp) * PW + 2 * t_tx + t_cp) * 4;
+    const int p_base = (t_half * PPIX + 2 * t_ty * PW + 2 * t_tx) * 4;
+    const int r_off[3] = {(t_rp ? 2 : 0) * PW * 4, (t_rp ? 1 : 2) * PW * 4, (t_rp ? 3 : 1) * PW * 4};
+    const int c_off[3] = {(t_cp ? 2 : 0) * 4, (t_cp ? 1 : 2) * 4, (t_cp ? 3 : 1) * 4};
+    const float s_r = t_rp ? -1.f : 1.f, s_c = t_cp ? -1.f : 1.f;
     constexpr int kVPos = 2 * 64 * 4;          // floats between consecutive positions of V / a filter slab
     const int v_off = ((((t_rp * 2) * 4 + t_cp * 2) * 2 + t_half) * 64 + t_tile) * 4;   // (xi, nu) = (2 rp, 2 cp)
 
     float4 d[3][3], tq[3];
-    auto tr_load = [&](const float *pb, int rr) {              // one row of the 3 x 3 raw float4
+    auto f4fma = [](float s_, float4 b, float4 c) {
+        return make_float4(fmaf(s_, b.x, c.x), fmaf(s_, b.y, c.y), fmaf(s_, b.z, c.z), fmaf(s_, b.w, c.w));
+    };
+    auto tr_load = [&](const float *pb, int rr) {              // one of the rows A, B, C: columns A, B, C
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc)
-            d[rr][cc] = *reinterpret_cast<const float4 *>(pb + p_off + (rr * PW + cc) * 4);
+            d[rr][cc] = *reinterpret_cast<const float4 *>(pb + p_base + r_off[rr] + c_off[cc]);
     };
-    auto tr_rows = [&](int q) {                                // t = (B^T d) row xi = 2 rp + q
+    auto tr_rows = [&](int q) {                                // t = row 2 rp + q of (+-) B^T d
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            if (t_rp == 0) tq[cc] = q == 0 ? f4sub(d[0][cc], d[2][cc]) : f4add(d[1][cc], d[2][cc]);
-            else           tq[cc] = q == 0 ? f4sub(d[1][cc], d[0][cc]) : f4sub(d[0][cc], d[2][cc]);
-        }
+        for (int cc = 0; cc < 3; ++cc)
+            tq[cc] = q == 0 ? f4sub(d[0][cc], d[1][cc]) : f4fma(s_r, d[1][cc], d[2][cc]);
     };
-    auto tr_store = [&](float *vbuf, int q) {                  // V[xi][2 cp], V[xi][2 cp + 1] = (t B)
+    auto tr_store = [&](float *vbuf, int q) {                  // V[xi][2 cp], V[xi][2 cp + 1]
         float *vb = vbuf + v_off + q * 4 * kVPos;
-        if (t_cp == 0) {
-            *reinterpret_cast<float4 *>(vb) = f4sub(tq[0], tq[2]);
-            *reinterpret_cast<float4 *>(vb + kVPos) = f4add(tq[1], tq[2]);
-        } else {
-            *reinterpret_cast<float4 *>(vb) = f4sub(tq[1], tq[0]);
-            *reinterpret_cast<float4 *>(vb + kVPos) = f4sub(tq[0], tq[2]);
-        }
+        *reinterpret_cast<float4 *>(vb) = f4sub(tq[0], tq[1]);
+        *reinterpret_cast<float4 *>(vb + kVPos) = f4fma(s_c, tq[1], tq[2]);
     };
     auto tr_piece = [&](const float *pb, float *vbuf, int k) { // 7 pieces
         if (k < 3) tr_load(pb, k);
@@ -192,11 +203,11 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
 
     const int a_off = (wp * 8 * 2 * 64 + lhi * 64 + wa * 32 + l31) * 4;
     const int b_off = (wp * 8 * 2 * BN + lhi * BN + wb * 32 + l31) * 4;
-    for (int c = 0; c < nchunks; ++c) {
+    auto chunk = [&](int c, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
         const int buf = c & 1;
         // invariant: V[buf], Bs[buf] hold chunk c; patch[buf ^ 1] holds the raw chunk c + 1; the
         // registers hold the raw chunk c + 2; every wave is past its reads of chunk c - 1
-        const bool more = c + 1 < nchunks;
         auto copies = [&]() {                  // this wave's share of the chunk's global traffic
             if (c + 2 < nchunks) store_patch(patch + buf * kPatchF);
             if (c + 3 < nchunks) fetch_patch(c + 3);
@@ -246,7 +257,10 @@ __global__ __launch_bounds__(kThreads) void wino_conv_nhwc(WinoArgs args, const 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab c + 1 (this wave's pieces) landed
         if (!(WINO_ABLATE & 8)) __syncthreads();
-    }
+    };
+    // steady state without a branch per piece; the last chunk has nothing to prepare
+    for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
+    chunk(nchunks - 1, std::false_type{});
 
     // ---- inverse transform: lane = cout, register e = tile.  This wave holds transform rows
     // xi = 2 wp, 2 wp + 1: T[xi][j] = (M A)[xi][j], and its share of Y = A^T T is
@@ -335,7 +349,9 @@ __global__ void wino_weights(const float *__restrict__ w, long s_co, long s_ci, 
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             const int pos = xi * 4 + nu;
-            U[((((size_t)pos * nchunks + ci / CK) * 2 + (ci % CK) / 4) * Cout + co) * 4 + (ci & 3)] = u[nu];
+            // row 3 / column 3 of the input transform are computed negated (wino_conv_nhwc): same sign here
+            const float sg = ((xi == 3) != (nu == 3)) ? -1.f : 1.f;
+            U[((((size_t)pos * nchunks + ci / CK) * 2 + (ci % CK) / 4) * Cout + co) * 4 + (ci & 3)] = sg * u[nu];
         }
     }
 }
