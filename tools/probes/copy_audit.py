@@ -1,13 +1,11 @@
 import os, sys, argparse, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import bench
+from datr_amd.training import Stepper, synthetic_batch
 from torch.profiler import profile, ProfilerActivity
-args = argparse.Namespace(tuned_gemm=True, channels_last=True, flat_grads=False)
 dev = torch.device("cuda:0")
-tr = bench.Trainer(args, dev, False)
-samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
-samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
+tr = Stepper(dev)
+samples, targets = synthetic_batch(2, 800, 1333, 10, dev, seed=1)
 for _ in range(4):
     tr.step(samples, targets)
 torch.cuda.synchronize()

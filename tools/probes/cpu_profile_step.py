@@ -2,12 +2,10 @@
 import os, sys, cProfile, pstats, argparse, io
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import bench
-args = argparse.Namespace(tuned_gemm=True, channels_last=True, flat_grads=False)
+from datr_amd.training import Stepper, synthetic_batch
 dev = torch.device("cuda:0")
-tr = bench.Trainer(args, dev, False)
-samples, targets = bench.synthetic_batch(2, 800, 1333, 10, dev, seed=1)
-samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
+tr = Stepper(dev)
+samples, targets = synthetic_batch(2, 800, 1333, 10, dev, seed=1)
 for _ in range(6):
     tr.step(samples, targets)
 torch.cuda.synchronize()
@@ -19,7 +17,7 @@ for _ in range(10):
     t0 = time.perf_counter(); out = tr.model(samples, targets)
     t1 = time.perf_counter(); ld = tr.criterion(out, targets); loss = weighted_total(ld, tr.criterion.weight_dict)
     t2 = time.perf_counter(); tr.optimizer.zero_grad(); loss.backward()
-    t3 = time.perf_counter(); torch.nn.utils.clip_grad_norm_(tr.model.parameters(), tr.max_norm)
+    t3 = time.perf_counter(); torch.nn.utils.clip_grad_norm_(tr.model.parameters(), tr.state.cfg.clip_max_norm)
     t4 = time.perf_counter(); tr.optimizer.step()
     t5 = time.perf_counter()
     for i, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5))):
