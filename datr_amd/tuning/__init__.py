@@ -66,6 +66,8 @@ def enable(path: str = RESULTS, tune: bool = False) -> bool:
         return False
     t.enable(True)
     t.tuning_enable(bool(tune))
+    if not tune and hasattr(t, "write_file_on_exit"):
+        t.write_file_on_exit(False)      # lookup only: nothing to record, and N ranks must not race on a file
     if os.path.exists(path):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
