@@ -58,6 +58,8 @@ _SIGNATURES = {
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_resize_bilinear_u8": [_vp, _i64, _i64, ctypes.c_int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp,
                                 _vp, _vp],
+    "datr_pixel_ops_u8": [_vp, _vp, _i64, _vp, _i64, _vp, _vp],
+    "datr_box_blur_u8": [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint32, ctypes.c_uint32, _i64, _vp],
     "datr_groupnorm_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _vp,
                                         _vp, _vp],
     "datr_groupnorm_nhwc_backward_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp],

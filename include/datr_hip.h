@@ -237,6 +237,40 @@ int datr_resize_bilinear_u8(const uint8_t *src, int64_t H, int64_t W, int flip, 
                             int64_t ksy, int64_t oh, int64_t ow, uint8_t *tmp, uint8_t *dst, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Photometric ("strong") augmentation of uint8 [H, W, 3] images, bit-exact with Pillow -- the
+ * pixel work of the reference's make_coco_strong_transforms (/root/reference/datasets/DAcoco.py:
+ * 330-360: torchvision ColorJitter / RandomGrayscale on PIL images = ImageEnhance.Brightness /
+ * Contrast / Color, an HSV round trip, Image.convert("L"); GaussianBlur = ImageFilter.GaussianBlur).
+ *
+ * datr_pixel_ops_u8 applies a chain of up to DATR_PIXEL_OPS_MAX per-pixel operations in one pass
+ * (src may equal dst): BRIGHTNESS / CONTRAST / SATURATION blend towards black / the mean grey of
+ * the image AT THAT POINT OF THE CHAIN / the pixel's luma with factor `alpha` (Image.blend's
+ * float32 arithmetic); HUE adds the byte `shift` to the H of Pillow's 8-bit HSV; GRAYSCALE
+ * replaces the pixel by its luma.  `sums`: DATR_PIXEL_OPS_MAX uint64 of device scratch, needed
+ * (non-NULL) when the chain holds a CONTRAST step.  src / dst 4-byte aligned. */
+#define DATR_PIXEL_OPS_MAX    8
+#define DATR_PIXEL_BRIGHTNESS 0
+#define DATR_PIXEL_CONTRAST   1
+#define DATR_PIXEL_SATURATION 2
+#define DATR_PIXEL_HUE        3
+#define DATR_PIXEL_GRAYSCALE  4
+typedef struct {
+    int32_t code;  /* DATR_PIXEL_* */
+    float alpha;   /* blend factor (BRIGHTNESS / CONTRAST / SATURATION) */
+    int32_t shift; /* HUE: (int)(hue_factor * 255) & 0xFF */
+} datr_pixel_op;
+int datr_pixel_ops_u8(const uint8_t *src, uint8_t *dst, int64_t npix, const datr_pixel_op *ops, int64_t nops,
+                      uint64_t *sums, void *stream);
+
+/* Pillow's ImagingBoxBlur on a uint8 [H, W, 3] image: `passes` horizontal passes of the extended
+ * box blur, then `passes` vertical ones, edges clamped; `radius` = integer part of the box radius,
+ * ww / fw = its 8.24 fixed-point inner / far weights (host-computed as libImaging BoxBlur.c does,
+ * datr_amd/strong_aug.py::box_weights; ImageFilter.GaussianBlur(sigma) = 3 passes with the radius
+ * of gaussian_box_radius(sigma)).  src != dst.  passes * (radius + 1) > ~60: DATR_EUNSUPPORTED. */
+int datr_box_blur_u8(const uint8_t *src, uint8_t *dst, int64_t H, int64_t W, int64_t radius, uint32_t ww,
+                     uint32_t fw, int64_t passes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * FFN backward, the non-GEMM pass: given h = relu(linear1(x)) saved by the forward and
  * dh = d loss / d h, computes IN PLACE dh <- dh * (h > 0) and db[c] = sum_r dh[r, c]
  * (the bias gradient of linear1) in one pass over HBM

@@ -183,6 +183,39 @@ def install(neutralise_cuda: bool = True):
     for n in ("Compose", "ToTensor", "Normalize", "RandomCrop", "RandomErasing", "ColorJitter",
               "RandomGrayscale", "RandomApply", "ToPILImage", "GaussianBlur", "RandomResizedCrop"):
         setattr(tfm, n, type(n, (), {"__init__": lambda self, *a, **k: None}))
+    # What torchvision.transforms.functional does for PIL images (the only kind the reference's data
+    # pipeline, datasets/da_transforms.py, hands it): thin wrappers over Pillow and two tensor ops.
+    # Used by tests/golden/make_golden_transforms.py to run the reference's own transform classes.
+    def _tv_resize(img, size, interpolation=None):
+        from PIL import Image
+        return img.resize((int(size[1]), int(size[0])), Image.BILINEAR)
+
+    def _tv_to_tensor(img):
+        import numpy as np
+        a = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+        return a.permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    def _tv_normalize(t, mean, std):
+        m = torch.as_tensor(mean, dtype=t.dtype).view(-1, 1, 1)
+        s_ = torch.as_tensor(std, dtype=t.dtype).view(-1, 1, 1)
+        return t.clone().sub_(m).div_(s_)
+
+    def _tv_hflip(img):
+        from PIL import Image
+        return img.transpose(Image.FLIP_LEFT_RIGHT)
+
+    tfm_f.resize, tfm_f.to_tensor, tfm_f.normalize, tfm_f.hflip = _tv_resize, _tv_to_tensor, _tv_normalize, _tv_hflip
+    tfm_f.crop = lambda img, top, left, height, width: img.crop((left, top, left + width, top + height))
+
+    def _random_crop_params(img, output_size):                 # torchvision.transforms.RandomCrop.get_params
+        w, h = img.size
+        th, tw = output_size
+        if w == tw and h == th:
+            return 0, 0, h, w
+        i = torch.randint(0, h - th + 1, size=(1,)).item()
+        j = torch.randint(0, w - tw + 1, size=(1,)).item()
+        return i, j, th, tw
+    tfm.RandomCrop.get_params = staticmethod(_random_crop_params)
     dsets = _module("torchvision.datasets")
     dsets.CocoDetection = type("CocoDetection", (torch.utils.data.Dataset,), {})
     dsets.VisionDataset = type("VisionDataset", (torch.utils.data.Dataset,), {})
