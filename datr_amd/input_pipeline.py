@@ -8,8 +8,10 @@ uint8 HWC images instead (what the decoder / resize / flip stages hand over), mo
 of the bytes across PCIe, and builds the padded batch -- directly in the backbone's NHWC layout
 if asked -- and the mask in one kernel per image (csrc/preprocess.hip).  Same values bit for bit.
 `resize_uint8_on_device` is the RandomResize / RandomHorizontalFlip stage in front of it: Pillow's
-8-bit bilinear resampler restated (weights on the host, two small kernels), bit-exact; the
-strong-augmentation ops (ColorJitter, grayscale, blur) stay on the host.
+8-bit bilinear resampler restated (weights on the host, two small kernels), bit-exact.  The
+transform objects that drive it live in datr_amd/transforms.py, the strong-augmentation kernels
+(ColorJitter, grayscale, blur) in datr_amd/strong_aug.py; `collate_fn_da_on_device` is the
+reference's `collate_fn_da` for their uint8 device output.
 """
 from __future__ import annotations
 
@@ -62,6 +64,21 @@ def collate_uint8_on_device(images: Sequence[torch.Tensor], device=None, mean=IM
             d.record_stream(torch.cuda.current_stream(device))
     padded = any(int(im.shape[0]) != Hp or int(im.shape[1]) != Wp for im in images)
     return NestedTensor(batch, mask, padded)
+
+
+def collate_fn_da_on_device(batch, device=None, channels_last: bool = True):
+    """`collate_fn_da` (/root/reference/util/misc.py:291-300) for items whose images are still uint8
+    [H, W, 3] (transforms.da_item): samples = source images followed by target images in one padded
+    batch; samples_strong_aug = source images followed by the strongly augmented target images (None
+    when the items carry no strong image).  Returns (samples, source_labels, target_labels,
+    samples_strong_aug)."""
+    source_imgs, source_labels, target_imgs, target_labels, target_imgs_strong_aug = list(zip(*batch))
+    samples = collate_uint8_on_device(source_imgs + target_imgs, device=device, channels_last=channels_last)
+    samples_strong_aug = None
+    if target_imgs_strong_aug[0] is not None:
+        samples_strong_aug = collate_uint8_on_device(source_imgs + target_imgs_strong_aug, device=device,
+                                                     channels_last=channels_last)
+    return samples, source_labels, target_labels, samples_strong_aug
 
 
 def get_size_with_aspect_ratio(image_size_wh, size, max_size=None):

@@ -161,5 +161,22 @@ def make_train_transforms(scales=(480, 512, 544, 576, 608, 640, 672, 704, 736, 7
     ])
 
 
-__all__ = ["Compose", "RandomHorizontalFlip", "RandomResize", "RandomSizeCrop", "RandomSelect", "NormalizeBoxes",
+def dataset_item(image, target, transforms, strong_transforms=None):
+    """The augmentation half of the reference's `CocoDetection.__getitem__` (DAcoco.py:391-398):
+    the strong transforms see the image BEFORE the geometric ones, then the pair shares them."""
+    image_strong_aug = strong_transforms(image) if strong_transforms is not None else None
+    if transforms is not None:
+        image, image_strong_aug, target = transforms(image, image_strong_aug, target)
+    return image, image_strong_aug, target
+
+
+def da_item(source, target, transforms, strong_transforms=None):
+    """`DADataset.__getitem__` (DAcoco.py:655-670) for decoded (image, target) pairs: the source
+    item never gets a strong copy; the target's labels travel along only for their sizes."""
+    source_img, _, source_label = dataset_item(source[0], source[1], transforms)
+    target_img, target_img_strong_aug, target_label = dataset_item(target[0], target[1], transforms, strong_transforms)
+    return source_img, source_label, target_img, target_label, target_img_strong_aug
+
+
+__all__ = ["dataset_item", "da_item", "Compose", "RandomHorizontalFlip", "RandomResize", "RandomSizeCrop", "RandomSelect", "NormalizeBoxes",
            "make_train_transforms", "hflip", "crop", "resize", "IMAGENET_MEAN", "IMAGENET_STD"]

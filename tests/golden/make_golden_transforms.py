@@ -67,3 +67,53 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---- a whole domain-adaptation batch: CocoDetection.__getitem__ (augmentation half) + DADataset + collate_fn_da ----
+def make_da_batch():
+    """tests/golden/da_batch.npz: two (source, target) pairs through the reference's train transforms
+    (the target with a strongly augmented PIL copy -- fixed Pillow calls here, torchvision's random
+    ColorJitter is absent) and the reference's `collate_fn_da` (/root/reference/util/misc.py:291-300)."""
+    from PIL import ImageEnhance, ImageFilter
+    import util.misc as ref_misc
+    args = argparse.Namespace(data_aug_scales=[24, 28, 32], data_aug_max_size=50,
+                              data_aug_scales2_resize=[20, 25, 30], data_aug_scales2_crop=[18, 30])
+    tf = make_coco_transforms("train", args=args)
+    out = {}
+    for k, v in vars(args).items():
+        out["cfg/" + k] = np.asarray(v, dtype=np.int64)
+    random.seed(5)
+    torch.manual_seed(5)
+    items = []
+    for n in range(2):
+        pair = []
+        for dom in ("source", "target"):
+            rng = np.random.default_rng(100 + 2 * n + (dom == "target"))
+            h, w = int(rng.integers(36, 48)), int(rng.integers(48, 64))
+            img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            boxes = np.array([[3., 4., w * 0.6, h * 0.7], [w * 0.3, h * 0.2, w - 2., h - 3.]], dtype=np.float32)
+            out[f"{dom}{n}/image"], out[f"{dom}{n}/boxes"] = img, boxes
+            b = torch.from_numpy(boxes)
+            tgt = {"boxes": b, "labels": torch.tensor([1 + n, 3]), "area": (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]),
+                   "iscrowd": torch.zeros(2, dtype=torch.int64), "size": torch.tensor([h, w])}
+            pil = Image.fromarray(img)
+            strong = None
+            if dom == "target":
+                strong = ImageEnhance.Contrast(ImageEnhance.Color(pil).enhance(1.3)).enhance(0.8)
+                strong = strong.filter(ImageFilter.GaussianBlur(radius=1.1))
+            pair.append(tf(pil, strong, tgt))
+        (s_img, _, s_lab), (t_img, t_strong, t_lab) = pair
+        items.append((s_img, s_lab, t_img, t_lab, t_strong))
+    samples, source_labels, target_labels, strong = ref_misc.collate_fn_da(items)
+    out["samples/tensors"], out["samples/mask"] = samples.tensors.numpy(), samples.mask.numpy()
+    out["strong/tensors"], out["strong/mask"] = strong.tensors.numpy(), strong.mask.numpy()
+    for n in range(2):
+        for dom, labs in (("source", source_labels), ("target", target_labels)):
+            for key in ("boxes", "labels", "size"):
+                out[f"{dom}{n}/out_{key}"] = labs[n][key].numpy()
+    np.savez_compressed(os.path.join(OUT, "da_batch.npz"), **out)
+    print("wrote da_batch.npz", os.path.getsize(os.path.join(OUT, "da_batch.npz")), "bytes", samples.tensors.shape)
+
+
+if __name__ == "__main__":
+    make_da_batch()
