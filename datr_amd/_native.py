@@ -58,6 +58,7 @@ _SIGNATURES = {
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_resize_bilinear_u8": [_vp, _i64, _i64, ctypes.c_int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp,
                                 _vp, _vp],
+    "datr_conv3x3_wino_wgrad_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "datr_pixel_ops_u8": [_vp, _vp, _i64, _vp, _i64, _vp, _vp],
     "datr_box_blur_u8": [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint32, ctypes.c_uint32, _i64, _vp],
     "datr_groupnorm_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _vp,
@@ -76,6 +77,11 @@ _SIGNATURES = {
 class WinoLevel(ctypes.Structure):
     """`datr_wino_level` of include/datr_hip.h."""
     _fields_ = [("x", _vp), ("y", _vp), ("gate", _vp), ("H", _i64), ("W", _i64)]
+
+
+class WinoWgradLevel(ctypes.Structure):
+    """`datr_wino_wgrad_level` of include/datr_hip.h."""
+    _fields_ = [("x", _vp), ("dy", _vp), ("H", _i64), ("W", _i64)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -102,6 +108,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_relu_bwd_bias_partial_rows.argtypes = [_i64]
     lib.datr_groupnorm_partial_floats.restype = ctypes.c_int64
     lib.datr_groupnorm_partial_floats.argtypes = [_i64, _i64, _i64, _i64]
+    lib.datr_wino_wgrad_partial_floats.restype = ctypes.c_int64
+    lib.datr_wino_wgrad_partial_floats.argtypes = [_vp, _i64, _i64, _i64, _i64]
     lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64
     lib.datr_wgrad_k256_scratch_floats.argtypes = []
     for name, argtypes in _SIGNATURES.items():

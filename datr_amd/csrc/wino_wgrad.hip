@@ -1,0 +1,351 @@
+// wino_wgrad.hip -- weight gradient of the 3x3 / stride 1 / pad 1 convolutions in the Winograd
+// F(2x2, 3x3) domain on the MFMA units, exact fp32, NHWC: `FCDiscriminator_img`'s three 3x3 layers
+// (/root/reference/models/dino/DA_utils.py:61-79, all pyramid levels of all 2B images,
+// dino.py:351-359) and conv2 of the trainable ResNet bottlenecks (backbone.py:109-128).
+//
+//   forward  Y = A^T [ (G g G^T) o (B^T d B) ] A   per 2x2 output tile, summed over input channels
+//   =>  dL/dg = G^T [ sum_tiles (A dY A^T) o (B^T d B) ] G
+// i.e. for each of the 16 transform positions a [Cout x tiles] x [tiles x Cin] product (2.25x fewer
+// multiplies than the direct weight gradient), then a 4x4 -> 3x3 fold per (cout, cin).
+//
+// Work split: a workgroup owns a 64 cout x 64 cin block of all 16 positions (8 waves x 2 positions x
+// 2x2 accumulator blocks of v_mfma_f32_32x32x2_f32 = 128 accumulator registers) for one SEGMENT of
+// tiles (split-K; the tiles of all pyramid levels, in chunks of 8, form one index space that is cut
+// into equal segments, ~one workgroup per CU in flight) and writes its partial sums; `wino_wgrad_fold` adds the segments in a fixed order
+// (deterministic, unlike an atomic accumulation) and applies G^T . G.
+// Tiles go by in chunks of 8, double-buffered in LDS with one barrier per chunk: waves 0-3 fetch the
+// 4x4 input patches of the next chunk (thread = tile x 4 channels x two of the four transform rows),
+// waves 4-7 the 2x2 dY tiles (raw buffer loads, out-of-image pixels read as zero), transform what they
+// fetched and write it into the operand layout [pos][row][8 tiles], in which an MFMA lane reads the four k-steps of a
+// chunk with ONE ds_read_b128 (k-step j pairs tile j with tile j + 4).  LDS rows are channels in the
+// order row = 16 (c % 4) + c / 4, and the two 4-tile halves of a row are swapped when bit 3 of the
+// row is set: writes (b32) and reads (b128) are then bank-conflict free.  The partial sums keep that
+// row order; the fold kernel undoes it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <type_traits>
+
+#include "datr_hip.h"
+
+#ifndef WGRAD_ABLATE
+#define WGRAD_ABLATE 0     // development only (wrong results): 1 no fetch, 2 no transform, 4 no multiply, 8 no loop barrier
+#endif
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 512;                   // 8 waves, two per SIMD: 128 accumulator + <= 128 other registers each
+constexpr int PW = 2;                           // positions per wave
+constexpr int BC = 64;                          // channels per block (both cout and cin)
+constexpr int TK = 8;                           // tiles per chunk
+constexpr int kOpF = 16 * BC * TK;              // floats per operand buffer: [pos][row][8]
+constexpr int kLdsBytes = 4 * kOpF * 4;         // U', V, double-buffered: 128 KiB
+constexpr unsigned kOOB = 0x80000000u;
+
+// Tiles of a level: t = (n * TH + ty) * TW + tx, padded to whole chunks; the levels' chunks are laid end
+// to end (`first` = a level's first chunk) and a segment is a range of that chunk space, so a chunk
+// never straddles two levels but a segment may.
+struct Level { const float *x; const float *dy; int H, W, TH, TW, tiles, first; };
+struct Args {
+    Level lv[DATR_WINO_MAX_LEVELS];
+    int nlevels, chunks, nseg, N, Cin, Cout;
+};
+
+__global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Us = smem;                           // [2][16][64][8]  A dY A^T
+    float *Vs = smem + 2 * kOpF;                // [2][16][64][8]  B^T d B
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int Cin = args.Cin, Cout = args.Cout;
+    const int ci0 = blockIdx.x * BC, co0 = blockIdx.y * BC;
+    // this workgroup's chunks [cbeg, cend): equal shares of the chunk space
+    const int cbeg = (int)((long long)args.chunks * blockIdx.z / args.nseg);
+    const int cend = (int)((long long)args.chunks * (blockIdx.z + 1) / args.nseg);
+
+    // ---- fetch role: thread = (tile ft, channel quad fq, half fh of the transform rows); waves 0-3 take
+    // the input patches (is_x), waves 4-7 the dY tiles
+    const bool is_x = wave < 4;
+    const int ft = tid & 7, fq = (tid >> 3) & 15, fh = (tid >> 7) & 1;
+    const unsigned xchan = (unsigned)((ci0 + fq * 4) * 4), ychan = (unsigned)((co0 + fq * 4) * 4);
+    int lvl = -1, H = 0, W = 0, TH = 0, TW = 0, ltiles = 0, lend = 0;     // current level (uniform)
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(args.lv[0].x), 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = rx;
+    int fc = cbeg;                                 // chunk the next fetch() reads
+    int tt = 0, tx = 0, ty = 0, tn = 0;            // this thread's tile of that chunk
+    float4 rawx[12], rawy[4];                      // fetched input patch rows (waves 0-3) / dY tile (waves 4-7)
+
+    auto fetch = [&](auto role_x) {
+        if (fc >= lend) {                          // (first call, or) the chunk opens the next level
+            do { ++lvl; lend = (lvl + 1 < args.nlevels) ? args.lv[lvl + 1].first : args.chunks; } while (fc >= lend);
+            const Level L = args.lv[lvl];
+            H = L.H; W = L.W; TH = L.TH; TW = L.TW; ltiles = L.tiles;
+            rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, args.N * H * W * Cin * 4, 0x00020000);
+            ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.dy), 0, args.N * H * W * Cout * 4, 0x00020000);
+            tt = (fc - L.first) * TK + ft;
+            tx = tt % TW; ty = (tt / TW) % TH; tn = tt / (TW * TH);
+        }
+        const bool live = tt < ltiles;
+        if constexpr (decltype(role_x)::value) {
+            const int y0 = 2 * ty - 1 + fh, x0 = 2 * tx - 1;           // rows y0 .. y0 + 2, columns x0 .. x0 + 3
+            unsigned coff[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) coff[b] = (x0 + b >= 0 && x0 + b < W) ? (unsigned)((x0 + b) * Cin * 4) + xchan : kOOB;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int y = y0 + a;
+                const bool rv = live && y >= 0 && y < H;
+                const unsigned roff = (unsigned)((tn * H + y) * W) * (unsigned)(Cin * 4);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const unsigned off = (rv && coff[b] != kOOB) ? roff + coff[b] : kOOB;
+                    rawx[a * 4 + b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int y = 2 * ty + a, x = 2 * tx + b;
+                    const unsigned off = (live && y < H && x < W)
+                        ? (unsigned)(((tn * H + y) * W + x)) * (unsigned)(Cout * 4) + ychan : kOOB;
+                    rawy[a * 2 + b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
+                }
+        }
+        // the same thread's tile of the next chunk
+        ++fc; tt += TK; tx += TK;
+        while (tx >= TW) { tx -= TW; if (++ty == TH) { ty = 0; ++tn; } }
+    };
+
+    // LDS float index of (pos, row, tile): halves swapped on bit 3 of the row
+    const int frow_sw = (fq >> 3) & 1;
+    const int fslot = (((ft >> 2) ^ frow_sw) << 2) + (ft & 3);
+    auto put = [&](float *buf, int pos, float4 v) {             // channels 4 fq + e -> rows 16 e + fq
+        float *p = buf + (pos * BC + fq) * TK + fslot;
+        p[0 * 16 * TK] = v.x; p[1 * 16 * TK] = v.y; p[2 * 16 * TK] = v.z; p[3 * 16 * TK] = v.w;
+    };
+    auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+    auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    auto neg = [](float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); };
+
+    // the transform of the fetched chunk -> operand buffer `buf`
+    auto transform = [&](int buf, auto role_x) {
+        if constexpr (decltype(role_x)::value) {
+            // rows fetched: patch rows fh .. fh + 2.  B^T rows: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+            float *dst = Vs + buf * kOpF;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int xi = 2 * fh + x;
+                float4 R[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 r0 = rawx[0 * 4 + b], r1 = rawx[1 * 4 + b], r2 = rawx[2 * 4 + b];
+                    if (fh == 0) R[b] = (x == 0) ? sub(r0, r2) : add(r1, r2);
+                    else         R[b] = (x == 0) ? sub(r1, r0) : sub(r0, r2);
+                }
+                put(dst, xi * 4 + 0, sub(R[0], R[2]));
+                put(dst, xi * 4 + 1, add(R[1], R[2]));
+                put(dst, xi * 4 + 2, sub(R[2], R[1]));
+                put(dst, xi * 4 + 3, sub(R[1], R[3]));
+            }
+        } else {
+            // A rows: xi 0: y0, 1: y0 + y1, 2: y0 - y1, 3: -y1  (rows of the 2x2 dY tile), same on columns
+            float *dst = Us + buf * kOpF;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int xi = 2 * fh + x;
+                float4 S[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float4 y0 = rawy[b], y1 = rawy[2 + b];
+                    if (fh == 0) S[b] = (x == 0) ? y0 : add(y0, y1);
+                    else         S[b] = (x == 0) ? sub(y0, y1) : neg(y1);
+                }
+                put(dst, xi * 4 + 0, S[0]);
+                put(dst, xi * 4 + 1, add(S[0], S[1]));
+                put(dst, xi * 4 + 2, sub(S[0], S[1]));
+                put(dst, xi * 4 + 3, neg(S[1]));
+            }
+        }
+    };
+
+    // ---- multiply role: wave w owns positions 2 w, 2 w + 1 (128 accumulator registers) ----------------
+    // (not zero-initialised: 256 zeros alive through the prologue would sit in ordinary registers and
+    // spill the fetch; the first chunk's first k-step multiplies onto the inline constant 0 instead)
+    f32x16 acc[PW][2][2];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int rslot = (lhi ^ ((l31 >> 3) & 1)) << 2;
+    auto multiply = [&](int buf, auto first) {
+        float4 a[PW][2], b[PW][2];
+#pragma unroll
+        for (int p = 0; p < PW; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = buf * kOpF + ((PW * wave + p) * BC + i * 32 + l31) * TK + rslot;
+                a[p][i] = *reinterpret_cast<const float4 *>(Us + off);
+                b[p][i] = *reinterpret_cast<const float4 *>(Vs + off);
+            }
+#pragma unroll
+        for (int p = 0; p < PW; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            reinterpret_cast<const float *>(&a[p][i])[k], reinterpret_cast<const float *>(&b[p][j])[k],
+                            (decltype(first)::value && k == 0) ? zero : acc[p][i][j], 0, 0, 0);
+    };
+
+    // Waves w and w + 4 share a SIMD, and every wave multiplies chunk c at the top of iteration c (the
+    // accumulators never sit in role-dependent control flow).  The dY waves then transform chunk c + 1
+    // BEFORE the closing barrier; the patch waves (the heavier transform) do theirs AFTER it, for chunk
+    // c + 2, while the dY wave of the same SIMD is already multiplying: the MFMA pipe is fed by one wave
+    // while the other does its VALU / LDS work.  Each fetch is issued right after the transform that
+    // frees its registers and has a whole multiply phase to land.
+    const int nchunks = cend - cbeg;               // >= 1: the host never makes more segments than chunks
+    const std::true_type X{};
+    const std::false_type Y{};
+    if (is_x) {
+        fetch(X); transform(0, X);
+        if (nchunks > 1) { fetch(X); transform(1, X); }
+        if (nchunks > 2) fetch(X);
+    } else {
+        fetch(Y); transform(0, Y);
+        if (nchunks > 1) fetch(Y);
+    }
+    __syncthreads();
+    auto iteration = [&](int c, auto first) {
+        if (!(WGRAD_ABLATE & 4) || decltype(first)::value) multiply(c & 1, first);
+        if (!is_x) {
+            if (!(WGRAD_ABLATE & 2) && c + 1 < nchunks) transform((c + 1) & 1, Y);
+            if (!(WGRAD_ABLATE & 1) && c + 2 < nchunks) fetch(Y);
+        }
+        if (!(WGRAD_ABLATE & 8)) __syncthreads();
+        if (is_x) {
+            if (!(WGRAD_ABLATE & 2) && c + 2 < nchunks) transform(c & 1, X);
+            if (!(WGRAD_ABLATE & 1) && c + 3 < nchunks) fetch(X);
+        }
+    };
+    iteration(0, std::true_type{});
+    for (int c = 1; c < nchunks; ++c) iteration(c, std::false_type{});
+
+    // ---- partial[segment][pos][cout row][cin row], rows in LDS order within each 64-block -----------
+    float *out = partial + (size_t)blockIdx.z * 16 * Cout * Cin;
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+                    out[((size_t)(PW * wave + p) * Cout + co0 + row) * Cin + ci0 + j * 32 + l31] = acc[p][i][j][r];
+                }
+}
+
+// dW[co][ci][r][s] = sum_{xi,nu} G[xi][r] G[nu][s] sum_segments partial[.][xi * 4 + nu][co][ci]
+__global__ __launch_bounds__(256) void wino_wgrad_fold(const float *__restrict__ partial, int nseg, int Cout, int Cin,
+                                                       float *__restrict__ dw, int64_t s_co, int64_t s_ci,
+                                                       int64_t s_r, int64_t s_s)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    // a thread per (cout, cin) in TRUE channel order: the 64 lanes of a wave read one 64-channel block of
+    // the row-ordered partials (a permutation of one contiguous 256 B line) and write contiguous weights
+    const int ci = idx % Cin, co = idx / Cin;
+    auto row = [](int c) { return (c & ~63) + 16 * (c & 3) + ((c & 63) >> 2); };
+    const size_t at = (size_t)row(co) * Cin + row(ci);
+    float M[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) M[p] = 0.f;
+    for (int s = 0; s < nseg; ++s)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) M[p] += partial[((size_t)(s * 16 + p)) * Cout * Cin + at];
+    // T[r][nu] = sum_xi G[xi][r] M[xi][nu];  G columns: (1, .5, .5, 0), (0, .5, -.5, 0), (0, .5, .5, 1)
+    float T[3][4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+        const float h = 0.5f * (M[4 + nu] + M[8 + nu]), d = 0.5f * (M[4 + nu] - M[8 + nu]);
+        T[0][nu] = M[nu] + h; T[1][nu] = d; T[2][nu] = h + M[12 + nu];
+    }
+    float *o = dw + co * s_co + ci * s_ci;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float h = 0.5f * (T[r][1] + T[r][2]), d = 0.5f * (T[r][1] - T[r][2]);
+        o[r * s_r + 0 * s_s] = T[r][0] + h;
+        o[r * s_r + 1 * s_s] = d;
+        o[r * s_r + 2 * s_s] = h + T[r][3];
+    }
+}
+
+// chunk space of the levels, and how many segments to cut it into: ~one workgroup per CU
+void plan(const datr_wino_wgrad_level *levels, int nlevels, int64_t N, int64_t blocks, Args &a) {
+    int chunks = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const int TH = (int)((levels[l].H + 1) / 2), TW = (int)((levels[l].W + 1) / 2);
+        const int tiles = (int)(N * TH * TW);
+        a.lv[l] = Level{levels[l].x, levels[l].dy, (int)levels[l].H, (int)levels[l].W, TH, TW, tiles, chunks};
+        chunks += (tiles + TK - 1) / TK;
+    }
+    a.nlevels = nlevels;
+    a.chunks = chunks;
+    const int64_t want = std::max<int64_t>(1, 256 / blocks);
+    a.nseg = (int)std::min<int64_t>(std::min<int64_t>(want, DATR_WINO_WGRAD_MAX_SEGMENTS), std::max(1, chunks / 4));
+}
+
+bool bad_dims(const datr_wino_wgrad_level *levels, int64_t nlevels, int64_t N, int64_t Cin, int64_t Cout) {
+    if (!levels || nlevels < 1 || nlevels > DATR_WINO_MAX_LEVELS || N < 1 || Cin < 1 || Cout < 1) return true;
+    for (int l = 0; l < nlevels; ++l)
+        if (levels[l].H < 1 || levels[l].W < 1) return true;
+    return false;
+}
+
+}  // namespace
+
+extern "C" int64_t datr_wino_wgrad_partial_floats(const datr_wino_wgrad_level *levels, int64_t nlevels, int64_t N,
+                                                  int64_t Cin, int64_t Cout) {
+    if (bad_dims(levels, nlevels, N, Cin, Cout) || Cin % BC || Cout % BC) return -1;
+    for (int l = 0; l < nlevels; ++l)
+        if (N * levels[l].H * levels[l].W * std::max(Cin, Cout) * 4 >= (int64_t)1 << 31) return -1;
+    Args a;
+    plan(levels, (int)nlevels, N, (Cin / BC) * (Cout / BC), a);
+    return (int64_t)a.nseg * 16 * Cin * Cout;
+}
+
+extern "C" int datr_conv3x3_wino_wgrad_nhwc_f32(const datr_wino_wgrad_level *levels, int64_t nlevels, int64_t N,
+                                                int64_t Cin, int64_t Cout, float *partial, float *dw, int64_t s_co,
+                                                int64_t s_ci, int64_t s_r, int64_t s_s, void *stream) {
+    if (bad_dims(levels, nlevels, N, Cin, Cout) || !partial || !dw) return DATR_EINVAL;
+    if (Cin % BC || Cout % BC) return DATR_EUNSUPPORTED;
+    Args a;
+    for (int l = 0; l < nlevels; ++l) {
+        if (!levels[l].x || !levels[l].dy) return DATR_EINVAL;
+        if (N * levels[l].H * levels[l].W * std::max(Cin, Cout) * 4 >= (int64_t)1 << 31) return DATR_EUNSUPPORTED;
+    }
+    plan(levels, (int)nlevels, N, (Cin / BC) * (Cout / BC), a);
+    a.N = (int)N; a.Cin = (int)Cin; a.Cout = (int)Cout;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_wgrad_nhwc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLdsBytes) != hipSuccess)
+            return DATR_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wino_wgrad_nhwc, dim3((unsigned)(Cin / BC), (unsigned)(Cout / BC), (unsigned)a.nseg), dim3(kThreads),
+                       kLdsBytes, st, a, partial);
+    const int64_t pairs = Cin * Cout;
+    hipLaunchKernelGGL(wino_wgrad_fold, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, partial, a.nseg, (int)Cout,
+                       (int)Cin, dw, s_co, s_ci, s_r, s_s);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}

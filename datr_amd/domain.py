@@ -16,11 +16,12 @@ import torch.nn.functional as F
 from torch import nn
 from torch.autograd.function import once_differentiable
 
-from .wino import _nhwc, wino_conv3x3, wino_filter
+from .wino import _nhwc, wino_conv3x3, wino_filter, wino_wgrad
 
 # own Winograd-on-MFMA path for the discriminator's 3x3 convolutions (csrc/wino.hip); 0 = the
 # library convolutions under autograd (A/B measurements)
 OWN_D_IMG = os.environ.get("DATR_OWN_D_IMG", "1") != "0"
+OWN_D_IMG_WGRAD = os.environ.get("DATR_OWN_D_IMG_WGRAD", "1") != "0"     # weight gradients in the Winograd domain too
 
 
 def decompose_features(srcs, masks, poss):
@@ -50,8 +51,10 @@ class _DImgPyramid(torch.autograd.Function):
     from dino.py:351-359).  Forward: three Winograd/MFMA launches (bias + LeakyReLU in the epilogue,
     all levels per launch) and the 128 -> 1 classifier.  Backward: per layer the data gradient is the
     same kernel on the transposed filter with the previous layer's LeakyReLU gate -- and, for the first
-    layer, the reversal's minus sign -- in its epilogue; weight / bias gradients come from the
-    library's weight-gradient convolution (torch.ops.aten.convolution_backward)."""
+    layer, the reversal's minus sign -- in its epilogue; the weight gradient of a layer is one launch
+    of csrc/wino_wgrad.hip over all levels (the same Winograd domain: sum over tiles of
+    (A dY A^T) o (B^T x B), folded by G^T . G), the bias gradient a column sum.  Only the 128 -> 1
+    classifier stays on the library."""
 
     SLOPE = 0.2
 
@@ -77,17 +80,22 @@ class _DImgPyramid(torch.autograd.Function):
         conv_bwd = torch.ops.aten.convolution_backward
 
         def wgrad(dzs, ins, w):
-            """sum over levels of (dW, db): the library's weight-gradient convolution; the bias
+            """sum over levels of (dW, db): the Winograd-domain weight gradient, all levels in one
+            launch (csrc/wino_wgrad.hip; the library's weight-gradient convolution per level for
+            channel counts it does not take); the bias
             gradient is the column sum of dz viewed [pixels, C] (NHWC), a deterministic two-stage own
             kernel (csrc/ffn.hip) instead of ATen's 64-workgroup reduction"""
             from .fused import column_sums
-            dw = db = None
+            dw = wino_wgrad(ins, dzs, w) if OWN_D_IMG_WGRAD else None
+            db = None
             for dz, a in zip(dzs, ins):
-                _, gw, _ = conv_bwd(dz, a, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                    [False, True, False])
                 gb = column_sums(dz.permute(0, 2, 3, 1).reshape(-1, dz.shape[1]))
-                dw = gw if dw is None else dw.add_(gw)
                 db = gb if db is None else db.add_(gb)
+            if dw is None:                                   # channel counts the kernel does not take
+                for dz, a in zip(dzs, ins):
+                    _, gw, _ = conv_bwd(dz, a, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                        [False, True, False])
+                    dw = gw if dw is None else dw.add_(gw)
             return dw, db
 
         # classifier (128 -> 1): library kernels; its data gradient is gated by hand

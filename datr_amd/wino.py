@@ -73,6 +73,37 @@ def wino_conv3x3(xs, u: torch.Tensor, cout: int, shift=None, scale=None, slope: 
     return ys
 
 
+def wino_wgrad(xs, dys, weight: torch.Tensor) -> torch.Tensor:
+    """Weight gradient of the 3x3 / stride 1 / pad 1 convolution with filter `weight` ([Cout, Cin, 3, 3],
+    any strides) summed over the levels: xs[i] the layer's input, dys[i] the gradient of its output,
+    channels_last [N, C, H, W] device tensors.  ONE launch of csrc/wino_wgrad.hip plus the fold; the
+    result has weight's shape and strides.  None when the channel counts are not multiples of 64."""
+    from . import _native
+    co, ci = weight.shape[:2]
+    if co % 64 or ci % 64 or tuple(weight.shape[2:]) != (3, 3):
+        return None
+    assert 1 <= len(xs) == len(dys) <= 4
+    N = xs[0].shape[0]
+    levels = (_native.WinoWgradLevel * len(xs))()
+    for i, (x, dy) in enumerate(zip(xs, dys)):
+        assert x.is_cuda and x.dtype == dy.dtype == torch.float32
+        assert x.shape == (N, ci) + tuple(dy.shape[2:]) and dy.shape[:2] == (N, co)
+        assert x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)
+        levels[i] = _native.WinoWgradLevel(x.data_ptr(), dy.data_ptr(), x.shape[2], x.shape[3])
+    floats = _native.lib.datr_wino_wgrad_partial_floats(ctypes.addressof(levels), len(xs), N, ci, co)
+    if floats < 0:
+        return None
+    partial = torch.empty(floats, device=weight.device, dtype=torch.float32)
+    dw = torch.empty_like(weight)                                   # preserves the strides
+    s = dw.stride()
+    with torch.cuda.device(weight.device):
+        rc = _native.lib.datr_conv3x3_wino_wgrad_nhwc_f32(ctypes.addressof(levels), len(xs), N, ci, co,
+                                                          partial.data_ptr(), dw.data_ptr(), s[0], s[1], s[2], s[3],
+                                                          _native.current_stream_ptr(weight.device))
+    _native.check(rc, "conv3x3_wino_wgrad_nhwc")
+    return dw
+
+
 class _Conv3x3BnRelu(torch.autograd.Function):
     """relu(conv3x3(x, w) * scale + shift), NHWC, frozen scale / shift (buffers, no gradient)."""
 
@@ -100,8 +131,10 @@ class _Conv3x3BnRelu(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             (dx,) = wino_conv3x3([dz], wino_filter(w, True), w.shape[1])
         if ctx.needs_input_grad[1]:
-            _, dw, _ = torch.ops.aten.convolution_backward(dz, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                           [False, True, False])
+            dw = wino_wgrad([x], [dz], w)
+            if dw is None:
+                _, dw, _ = torch.ops.aten.convolution_backward(dz, x, w, None, [1, 1], [1, 1], [1, 1], False,
+                                                               [0, 0], 1, [False, True, False])
         return dx, dw, None, None
 
 

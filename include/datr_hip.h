@@ -209,6 +209,23 @@ int datr_conv3x3_wino_nhwc_f32(const datr_wino_level *levels, int64_t nlevels, i
                                int64_t Cout, const float *u, const float *scale, const float *shift,
                                float slope, float gate_slope, float out_scale, void *stream);
 
+/* Weight gradient of the same convolutions in the Winograd domain (csrc/wino_wgrad.hip):
+ * dW = G^T [ sum over 2x2 tiles (A dY A^T) o (B^T x B) ] G, summed over all levels (they share the
+ * filter) -- replaces `torch.ops.aten.convolution_backward(dz, x, w, ..., [False, True, False])`, i.e.
+ * the weight-gradient half of autograd's backward of the reference's nn.Conv2d layers
+ * (/root/reference/models/dino/DA_utils.py:61-79, backbone.py:109-128).  x: [N, H, W, Cin], dy:
+ * [N, H, W, Cout] NHWC fp32 per level; Cin, Cout multiples of 64.  dw is OVERWRITTEN, addressed
+ * dw[co * s_co + ci * s_ci + r * s_r + s * s_s] (elements).  `partial`: scratch of
+ * datr_wino_wgrad_partial_floats(...) floats; the split-K segments are summed in a fixed order
+ * (deterministic, no atomics). */
+#define DATR_WINO_WGRAD_MAX_SEGMENTS 160
+typedef struct { const float *x; const float *dy; int64_t H, W; } datr_wino_wgrad_level;
+int64_t datr_wino_wgrad_partial_floats(const datr_wino_wgrad_level *levels, int64_t nlevels, int64_t N,
+                                       int64_t Cin, int64_t Cout);
+int datr_conv3x3_wino_wgrad_nhwc_f32(const datr_wino_wgrad_level *levels, int64_t nlevels, int64_t N,
+                                     int64_t Cin, int64_t Cout, float *partial, float *dw, int64_t s_co,
+                                     int64_t s_ci, int64_t s_r, int64_t s_s, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * GroupNorm on NHWC tensors (csrc/groupnorm.hip): `nn.GroupNorm(32, 256)` behind every input_proj
  * convolution (/root/reference/models/dino/dino.py:111-126), kept in the backbone's NHWC layout

@@ -185,3 +185,65 @@ def test_fold_frozen_bn_folds_and_backpropagates():
     torch.testing.assert_close(ws[0].grad, (2 * ss[0]).view(-1, 1, 1, 1).expand_as(ws[0]))
     torch.testing.assert_close(ws[2].grad, ss[2].view(-1, 1, 1, 1).expand_as(ws[2]))
     assert ws[1].grad is None and f[1] is fold_frozen_bn([(ws[1], ss[1])])[0]       # frozen: cached
+
+
+# ---- weight gradient in the Winograd domain (csrc/wino_wgrad.hip) ----------------------------------------
+def _wgrad_reference(xs, dys, w):
+    """float64 weight gradient of conv2d(x, w, padding=1), summed over the levels (autograd, CPU)."""
+    w64 = w.detach().double().cpu().requires_grad_(True)
+    total = 0.0
+    for x, dy in zip(xs, dys):
+        y = F.conv2d(x.detach().double().cpu(), w64, padding=1)
+        total = total + (y * dy.detach().double().cpu()).sum()
+    (g,) = torch.autograd.grad(total, w64)
+    return g
+
+
+@pytest.mark.parametrize("cin,cout,n,sizes", [
+    (64, 64, 1, [(8, 8)]),                       # one workgroup, tiles = one chunk per row
+    (64, 128, 2, [(7, 9)]),                      # odd sizes: half tiles at the right / bottom edge
+    (128, 64, 3, [(5, 3), (1, 1)]),              # tile rows shorter than a chunk, a 1-pixel level
+    (256, 128, 2, [(25, 42), (13, 21), (7, 11), (4, 6)]),   # a pyramid, several segments per level
+])
+def test_wino_wgrad_matches_float64_autograd(cin, cout, n, sizes):
+    from datr_amd.wino import wino_wgrad
+    g = torch.Generator().manual_seed(cin + cout + n)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to("cuda:0")
+    xs = [torch.randn(n, cin, h, ww, generator=g).to("cuda:0").contiguous(memory_format=torch.channels_last) for h, ww in sizes]
+    dys = [torch.randn(n, cout, h, ww, generator=g).to("cuda:0").contiguous(memory_format=torch.channels_last) for h, ww in sizes]
+    got = wino_wgrad(xs, dys, w)
+    assert got.shape == w.shape and got.stride() == w.stride()
+    want = _wgrad_reference(xs, dys, w)
+    err = (got.double().cpu() - want).abs().max().item()
+    assert err <= 2e-5 * want.abs().max().item() + 1e-5, err
+    # deterministic: the split-K segments are added in a fixed order
+    assert torch.equal(got, wino_wgrad(xs, dys, w))
+    # channels_last weights (the backbone's): same values at the weight's own strides
+    wcl = w.contiguous(memory_format=torch.channels_last)
+    got_cl = wino_wgrad(xs, dys, wcl)
+    assert got_cl.stride() == wcl.stride() and torch.equal(got_cl, got)
+
+
+def test_wino_wgrad_accuracy_is_that_of_the_library_at_the_discriminator_shape():
+    """256 -> 256 on the 50x84 level of 4 images: error against float64 no worse than 2x the
+    library's fp32 weight-gradient convolution."""
+    from datr_amd.wino import wino_wgrad
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(256, 256, 3, 3, generator=g).to("cuda:0")
+    x = torch.randn(4, 256, 50, 84, generator=g).to("cuda:0").contiguous(memory_format=torch.channels_last)
+    dy = (torch.randn(4, 256, 50, 84, generator=g) * 1e-3).to("cuda:0").contiguous(memory_format=torch.channels_last)
+    got = wino_wgrad([x], [dy], w)
+    _, lib, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                    [False, True, False])
+    want = _wgrad_reference([x], [dy], w)
+    e_own = (got.double().cpu() - want).abs().max().item()
+    e_lib = (lib.double().cpu() - want).abs().max().item()
+    assert e_own <= max(2 * e_lib, 1e-6 * want.abs().max().item()), (e_own, e_lib)
+
+
+def test_wino_wgrad_refuses_other_channel_counts():
+    from datr_amd.wino import wino_wgrad
+    w = torch.zeros(48, 64, 3, 3, device="cuda:0")
+    x = torch.zeros(1, 64, 8, 8, device="cuda:0").contiguous(memory_format=torch.channels_last)
+    dy = torch.zeros(1, 48, 8, 8, device="cuda:0").contiguous(memory_format=torch.channels_last)
+    assert wino_wgrad([x], [dy], w) is None
