@@ -30,7 +30,7 @@
 #include "datr_hip.h"
 
 #ifndef WGRAD_ABLATE
-#define WGRAD_ABLATE 0     // development only (wrong results): 1 no fetch, 2 no transform, 4 no multiply, 8 no loop barrier
+#define WGRAD_ABLATE 0     // development only (wrong results): 1 no fetch (16 / 32: none by the patch / dY waves), 2 no transform, 4 no multiply, 8 no loop barrier
 #endif
 
 namespace {
@@ -227,12 +227,12 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
         if (!(WGRAD_ABLATE & 4) || decltype(first)::value) multiply(c & 1, first);
         if (!is_x) {
             if (!(WGRAD_ABLATE & 2) && c + 1 < nchunks) transform((c + 1) & 1, Y);
-            if (!(WGRAD_ABLATE & 1) && c + 2 < nchunks) fetch(Y);
+            if (!(WGRAD_ABLATE & (1 | 32)) && c + 2 < nchunks) fetch(Y);
         }
         if (!(WGRAD_ABLATE & 8)) __syncthreads();
         if (is_x) {
             if (!(WGRAD_ABLATE & 2) && c + 2 < nchunks) transform(c & 1, X);
-            if (!(WGRAD_ABLATE & 1) && c + 3 < nchunks) fetch(X);
+            if (!(WGRAD_ABLATE & (1 | 16)) && c + 3 < nchunks) fetch(X);
         }
     };
     iteration(0, std::true_type{});
