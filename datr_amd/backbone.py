@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .fused import frozen_bn_act
-from .wino import conv3x3_bn_relu
+from .wino import conv3x3_bn_relu, conv3x3_own_wgrad
 from . import pointwise
 from .nested import NestedTensor
 
@@ -111,6 +111,10 @@ class Bottleneck(nn.Module):
         if self.conv2.stride == (1, 1):
             # 3x3 / stride 1 + frozen BN + ReLU: one Winograd/MFMA launch (csrc/wino.hip)
             out2 = conv3x3_bn_relu(out, self.conv2.weight, *self.bn2.scale_shift())
+            if out2 is None:                       # wide layers: library forward / data gradient, own weight gradient
+                y2 = conv3x3_own_wgrad(out, self.conv2.weight)
+                if y2 is not None:
+                    out2 = frozen_bn_act(y2, *self.bn2.scale_shift(), relu=True)
         out = out2 if out2 is not None else frozen_bn_act(self.conv2(out), *self.bn2.scale_shift(), relu=True)
         y3 = pointwise.conv1x1(out, self.conv3.weight) if nhwc else None
         if y3 is None:

@@ -138,6 +138,43 @@ class _Conv3x3BnRelu(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class _Conv3x3OwnWgrad(torch.autograd.Function):
+    """conv2d(x, w, stride 1, padding 1) with the library's forward and data gradient and the
+    Winograd-domain weight gradient (csrc/wino_wgrad.hip): the wide bottlenecks (layer3 / layer4),
+    whose small maps the library's forward kernels fill better than wino.hip's 16x16-pixel workgroups."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.conv2d(x, w, padding=1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _nhwc(dy)
+        dx = dw = None
+        conv_bwd = torch.ops.aten.convolution_backward
+        if ctx.needs_input_grad[0]:
+            dx, _, _ = conv_bwd(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])
+        if ctx.needs_input_grad[1]:
+            dw = wino_wgrad([x], [dy], w)
+            if dw is None:
+                _, dw, _ = conv_bwd(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])
+        return dx, dw
+
+
+def conv3x3_own_wgrad(x: torch.Tensor, w: torch.Tensor):
+    """Library convolution whose weight gradient is the own kernel, or None when that kernel does not
+    apply (the caller then calls the module)."""
+    co, ci = w.shape[:2]
+    if not (OWN_BACKBONE_3X3 and w.requires_grad and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and w.shape[2:] == (3, 3)
+            and ci % 64 == 0 and co % 64 == 0 and not torch.is_autocast_enabled()):
+        return None
+    return _Conv3x3OwnWgrad.apply(x, w)
+
+
 def conv3x3_bn_relu(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor):
     """relu(frozen_bn(conv2d(x, w, stride 1, padding 1))) in one Winograd/MFMA launch, or None when
     the shapes / dtype / device / layout are not the kernel's -- it is an NHWC kernel, an NCHW

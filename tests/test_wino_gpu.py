@@ -142,6 +142,29 @@ def test_backbone_bottleneck_routes_conv2_through_the_own_kernel(monkeypatch):
     torch.testing.assert_close(y_own, y_lib, rtol=1e-4, atol=1e-4)
 
 
+def test_wide_bottleneck_takes_library_forward_and_own_weight_gradient(monkeypatch):
+    """A layer3-sized bottleneck (256-channel conv2): forward and data gradient from the library, the
+    weight gradient of conv2 from csrc/wino_wgrad.hip -- same gradients as the all-library block."""
+    from datr_amd import backbone, wino
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    blk = backbone.Bottleneck(1024, 256, 1, backbone.FrozenBatchNorm2d, downsample=False).to(dev)
+    blk = blk.to(memory_format=torch.channels_last)
+    x = torch.randn(2, 1024, 25, 42, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(2, 1024, 25, 42, device=dev).contiguous(memory_format=torch.channels_last)
+    calls = []
+    real = wino.wino_wgrad
+    monkeypatch.setattr(wino, "wino_wgrad", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    params = [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight]
+    own = torch.autograd.grad(blk(x), [x] + params, go)
+    assert len(calls) == 1
+    monkeypatch.setattr(wino, "OWN_BACKBONE_3X3", False)
+    lib = torch.autograd.grad(blk(x), [x] + params, go)
+    assert len(calls) == 1
+    for a, b in zip(own, lib):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,hw,relu,bias", [(64, 256, (40, 52), False, False), (256, 64, (25, 42), True, True),
                                                    (512, 256, (13, 21), False, True), (2048, 512, (7, 11), True, True)])
 def test_conv1x1_as_gemm_matches_float64_convolution(cin, cout, hw, relu, bias, monkeypatch):
