@@ -14,7 +14,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
-    if e.key in ("aten::copy_", "aten::add", "aten::add_", "aten::sum", "aten::mul", "aten::div", "aten::cat", "aten::fill_"):
+    if e.key in ("aten::masked_fill", "aten::masked_fill_", "aten::copy_", "aten::add", "aten::add_", "aten::sum", "aten::mul", "aten::div", "aten::cat", "aten::fill_"):
         rows.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:90]))
 rows.sort(reverse=True)
 for r in rows[:40]:
