@@ -59,6 +59,7 @@ _SIGNATURES = {
     "datr_resize_bilinear_u8": [_vp, _i64, _i64, ctypes.c_int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp,
                                 _vp, _vp],
     "datr_conv3x3_wino_wgrad_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+    "datr_ema_update_f32": [_vp, _vp, _i64, ctypes.c_double, _vp],
     "datr_pixel_ops_u8": [_vp, _vp, _i64, _vp, _i64, _vp, _vp],
     "datr_box_blur_u8": [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint32, ctypes.c_uint32, _i64, _vp],
     "datr_groupnorm_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _vp,
@@ -110,6 +111,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_groupnorm_partial_floats.argtypes = [_i64, _i64, _i64, _i64]
     lib.datr_wino_wgrad_partial_floats.restype = ctypes.c_int64
     lib.datr_wino_wgrad_partial_floats.argtypes = [_vp, _i64, _i64, _i64, _i64]
+    lib.datr_ema_piece_elements.restype = ctypes.c_int64
+    lib.datr_ema_piece_elements.argtypes = []
     lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64
     lib.datr_wgrad_k256_scratch_floats.argtypes = []
     for name, argtypes in _SIGNATURES.items():

@@ -31,14 +31,46 @@ def copy_attr(a, b, include=(), exclude=()):
         setattr(a, k, v)
 
 
+class _DevicePlan:
+    """Device-resident tables of csrc/ema.hip for one (EMA model, model) pair: a `datr_ema_tensor`
+    per distinct float32 tensor and the work list of 4096-element pieces."""
+
+    def __init__(self, groups, device):
+        from . import _native
+        import numpy as np
+        piece = int(_native.lib.datr_ema_piece_elements())
+        tens = np.zeros((len(groups), 4), dtype=np.int64)
+        pieces = []
+        for i, (v, m, k) in enumerate(groups):
+            tens[i] = (v.data_ptr(), m.data_ptr(), v.numel(), k)
+            pieces += [(i, off) for off in range(0, v.numel(), piece)]
+        self.key = tuple(map(tuple, tens.tolist()))
+        self.npieces = len(pieces)
+        self.tensors = torch.from_numpy(tens).to(device)
+        self.pieces = torch.tensor(pieces, dtype=torch.int64).reshape(-1, 2).to(device)
+        self.device = device
+
+    def run(self, d: float):
+        from . import _native
+        with torch.cuda.device(self.device):
+            rc = _native.lib.datr_ema_update_f32(self.tensors.data_ptr(), self.pieces.data_ptr(), self.npieces,
+                                                 float(d), _native.current_stream_ptr(self.device))
+        _native.check(rc, "ema_update")
+
+
+_PLANS = {}      # id(ema_model) -> _DevicePlan
+
+
 @torch.no_grad()
 def _ema_update_(ema_model: nn.Module, model: nn.Module, d: float) -> None:
     """The reference walks the state_dict KEYS (EMA.py:46-50), so a tensor that appears under k
     keys -- the detection heads shared by the six decoder layers: `bbox_embed.0..5.*`,
     `class_embed.0..5.*` and their `transformer.decoder.*` aliases, 12 keys per tensor -- is
-    updated k times per call: v <- d^k v + (1 - d^k) m.  Reproduced here as ONE update with the
-    effective decay d^k per alias group (equal up to rounding), not "fixed" to a single update:
-    the teacher's heads are meant to track the student the way the reference's do."""
+    updated k times per call.  Reproduced, not "fixed" to a single update: every distinct tensor gets
+    `v *= d; v += (1. - d) * m` replayed k times, the reference's arithmetic bit for bit.  On the
+    device that is ONE launch of csrc/ema.hip over all float32 tensors (tables cached per EMA model
+    and rebuilt when a storage moved); tensors on the host (CPU runs) take the same arithmetic
+    through torch._foreach."""
     msd = _unwrap(model).state_dict()
     first, count = {}, {}
     for k, v in ema_model.state_dict().items():
@@ -47,15 +79,25 @@ def _ema_update_(ema_model: nn.Module, model: nn.Module, d: float) -> None:
             if ptr not in first:
                 first[ptr] = (v, msd[k].detach())
             count[ptr] = count.get(ptr, 0) + 1
-    by_k = {}
+    dev, host = [], {}
     for ptr, (v, m) in first.items():
-        dst, src = by_k.setdefault(count[ptr], ([], []))
-        dst.append(v)
-        src.append(m)
-    for k, (dst, src) in by_k.items():
-        dk = d ** k
-        torch._foreach_mul_(dst, dk)
-        torch._foreach_add_(dst, src, alpha=1.0 - dk)
+        if (v.is_cuda and m.is_cuda and v.dtype == m.dtype == torch.float32 and v.is_contiguous()
+                and m.is_contiguous() and v.numel() == m.numel() and v.device == m.device):
+            dev.append((v, m, count[ptr]))
+        else:
+            dst, src = host.setdefault(count[ptr], ([], []))
+            dst.append(v)
+            src.append(m)
+    if dev:
+        key = tuple((v.data_ptr(), m.data_ptr(), v.numel(), k) for v, m, k in dev)
+        plan = _PLANS.get(id(ema_model))
+        if plan is None or plan.key != key:
+            plan = _PLANS[id(ema_model)] = _DevicePlan(dev, dev[0][0].device)
+        plan.run(d)
+    for k, (dst, src) in host.items():
+        for _ in range(k):
+            torch._foreach_mul_(dst, d)
+            torch._foreach_add_(dst, torch._foreach_mul(src, 1.0 - d))
 
 
 class ModelEMA:

@@ -254,6 +254,20 @@ int datr_resize_bilinear_u8(const uint8_t *src, int64_t H, int64_t W, int flip, 
                             int64_t ksy, int64_t oh, int64_t ow, uint8_t *tmp, uint8_t *dst, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * EMA teacher update, all tensors in one launch (csrc/ema.hip): the reference's key walk
+ * `v *= d; v += (1. - d) * msd[k]` (/root/reference/models/dino/EMA.py:46-50, :123-128).
+ * `tensors` (device): one entry per DISTINCT float32 tensor of the EMA model's state_dict -- dst the
+ * EMA tensor, src the model's, `repeats` = the number of state_dict keys that alias it (the update
+ * is replayed that many times, as the key walk does).  `pieces` (device): the work list, one entry
+ * per datr_ema_piece_elements() elements of a tensor.  Both tables are built once by the caller.
+ * Arithmetic: fl(fl(v * d) + fl((1 - d) * m)) per replay, d and 1 - d rounded to float32. */
+typedef struct { float *dst; const float *src; int64_t numel; int64_t repeats; } datr_ema_tensor;
+typedef struct { int64_t tensor; int64_t offset; } datr_ema_piece;
+int64_t datr_ema_piece_elements(void);
+int datr_ema_update_f32(const datr_ema_tensor *tensors, const datr_ema_piece *pieces, int64_t npieces,
+                        double decay, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Photometric ("strong") augmentation of uint8 [H, W, 3] images, bit-exact with Pillow -- the
  * pixel work of the reference's make_coco_strong_transforms (/root/reference/datasets/DAcoco.py:
  * 330-360: torchvision ColorJitter / RandomGrayscale on PIL images = ImageEnhance.Brightness /

@@ -69,7 +69,7 @@ def test_ema_update_rule():
         m.weight.add_(1.0)
     ema.update(m)
     d = 0.9997 * (1 - np.exp(-1 / 2000))            # EMA.py:37
-    torch.testing.assert_close(ema.ema.weight, w0 * d + (1 - d) * m.weight.detach())
+    assert torch.equal(ema.ema.weight, w0 * d + (1 - d) * m.weight.detach())
     c = CosineEMA(m, decay_start=0.9, decay_end=0.99, total_epoch=10)
     c.update_decay(5)
     assert abs(c.decay - (0.99 - 0.09 * (np.cos(np.pi * 0.5) + 1) / 2)) < 1e-12
@@ -120,7 +120,7 @@ def test_ema_update_of_aliased_heads_follows_the_per_key_loop():
         aliases.setdefault(v.data_ptr(), []).append(k)
     assert max(len(v) for v in aliases.values()) == 12
     for (k, mine), (_, ref) in zip(teacher.ema.state_dict().items(), shadow.state_dict().items()):
-        torch.testing.assert_close(mine, ref, rtol=1e-6, atol=1e-7, msg=k)
+        assert torch.equal(mine, ref), k                      # the same arithmetic: bit for bit
     # and the aliased heads did move (1 - d^12) / (1 - d) ~ 7.8x further than a single update would have
     k = "class_embed.0.weight"
     single = expect[k] * d + (1 - d) * msd[k]

@@ -89,3 +89,51 @@ def test_device_nms_of_no_boxes_is_empty():
     out = batched_nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev),
                       torch.zeros(0, dtype=torch.int64, device=dev), 0.7)
     assert out.shape == (0,) and out.dtype == torch.int64
+
+
+def test_ema_update_kernel_is_the_key_walk_bit_for_bit():
+    """csrc/ema.hip (one launch over all tensors, aliased heads replayed 12 times in registers)
+    against the reference's loop `v *= d; v += (1. - d) * msd[k]` over the state_dict keys
+    (/root/reference/models/dino/EMA.py:46-50) run on the device with torch ops: identical bits, for
+    ModelEMA's ramped decay and CosineEMA's, over several updates; the tables survive a second model
+    and are rebuilt when storages move."""
+    import copy
+    from datr_amd import ema as ema_mod
+    from datr_amd.ema import CosineEMA, ModelEMA
+    from tests.helpers import build_model
+    dev = torch.device("cuda:0")
+    _, model, _, _ = build_model()
+    model.to(dev)
+    for teacher, decay in ((ModelEMA(model, decay=0.9996, updates=3000), None), (CosineEMA(model, 0.99, 0.9999, 10), 0.995)):
+        shadow = copy.deepcopy(teacher.ema)
+        calls = []
+        real = ema_mod._DevicePlan.run
+        ema_mod._DevicePlan.run = lambda self, d: (calls.append(self.npieces), real(self, d))[1]
+        try:
+            for it in range(3):
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.add_(0.03 * torch.randn_like(p))
+                d = teacher.decay(teacher.updates + 1) if decay is None else decay
+                if decay is not None:
+                    teacher.decay = decay
+                msd = model.state_dict()
+                with torch.no_grad():
+                    for k, v in shadow.state_dict().items():
+                        if v.dtype.is_floating_point:
+                            v *= d
+                            v += (1.0 - d) * msd[k].detach()
+                teacher.update(model)
+                for (k, mine), (_, ref) in zip(teacher.ema.state_dict().items(), shadow.state_dict().items()):
+                    assert torch.equal(mine, ref), (it, k)
+        finally:
+            ema_mod._DevicePlan.run = real
+        assert len(calls) == 3 and calls[0] > 10000            # one launch per update, ~49.6 M elements / 4096
+    # a storage that moved (load_state_dict keeps storages; .data = ... does not): the plan follows
+    teacher = ModelEMA(model, decay=0.999, updates=10)
+    teacher.update(model)
+    plan = ema_mod._PLANS[id(teacher.ema)]
+    w = model.transformer.level_embed
+    w.data = w.data.clone()
+    teacher.update(model)
+    assert ema_mod._PLANS[id(teacher.ema)] is not plan
