@@ -24,6 +24,7 @@ for r in rows:
     name[k] = r["Kernel_Name"]
 def family(n):
     if n.startswith("Cijk_"): return "hipBLASLt / rocBLAS GEMMs"
+    if "wino_wgrad_nhwc" in n: return "own Winograd weight gradient (wino_wgrad.hip)"
     if "wino_conv" in n: return "own Winograd convolutions (wino.hip)"
     if "wgrad_k256" in n: return "own 256x256 weight gradient (wgrad_k256.hip)"
     if "mha_" in n: return "own attention fwd + bwd (mha_fwd.hip, mha_bwd.hip)"
