@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import copy
 import math
+import weakref
 from typing import Optional
 
 import torch
@@ -411,6 +412,31 @@ class TransformerDecoder(nn.Module):
                 [r.transpose(0, 1) for r in ref_points]]
 
 
+_POS_TABLES = {}          # ids of the per-level position embeddings -> (weak refs, flattened [N, S, C] table)
+
+
+class _AddLevelEmbed(torch.autograd.Function):
+    """pos [N, S, C] (no gradient) + level_embed[level of token] -> [N, S, C]; sizes = tokens per level."""
+
+    @staticmethod
+    def forward(ctx, pos, level_embed, sizes):
+        ctx.sizes = sizes
+        rows = torch.repeat_interleave(level_embed[:len(sizes)],
+                                       torch.tensor(sizes, device=level_embed.device), dim=0, output_size=sum(sizes))
+        return pos + rows.unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, d):
+        from .fused import column_sums
+        per_token = d.sum(0) if d.shape[0] > 1 else d[0]                 # [S, C]
+        per_token = per_token.contiguous()
+        out, start = [], 0
+        for n in ctx.sizes:
+            out.append(column_sums(per_token[start:start + n]))
+            start += n
+        return None, torch.stack(out, 0), None
+
+
 class DeformableTransformer(nn.Module):
     def __init__(self, d_model=256, nhead=8, num_queries=300, num_encoder_layers=6,
                  num_unicoder_layers=0, num_decoder_layers=6, dim_feedforward=2048, dropout=0.0,
@@ -546,6 +572,37 @@ class DeformableTransformer(nn.Module):
     # that still costs a pass over value per layer.  Proposals / valid ratios keep using the mask.
     no_padding = False
 
+    def _level_positions(self, pos_embeds):
+        """cat_l(flatten(pos_l) + level_embed[l]) -> [N, S, C]
+        (/root/reference/models/dino/deformable_transformer.py:283-286).  On the device with
+        gradient-free position embeddings (the sine embedding) the flattened table is one cat -- kept
+        across steps when the embeddings are the cached per-shape tensors of an unpadded batch -- and
+        the level embedding is added by ONE broadcast add whose backward is a sum over the batch and
+        one deterministic column-sum launch per level (fused.column_sums), instead of four adds, a cat
+        and four ATen reductions over [N, tokens_l, C]."""
+        with_level = self.num_feature_levels > 1 and self.level_embed is not None
+        fast = (with_level and pos_embeds[0].is_cuda and pos_embeds[0].dtype == torch.float32
+                and not any(p.requires_grad for p in pos_embeds))
+        if not fast:
+            flat = [p.flatten(2).transpose(1, 2) for p in pos_embeds]
+            if with_level:
+                flat = [f + self.level_embed[lvl].view(1, 1, -1) for lvl, f in enumerate(flat)]
+            return torch.cat(flat, 1)
+        # keyed by the identity of the embedding tensors (weak references: a dead tensor's id may be reused)
+        tables = _POS_TABLES
+        key = tuple(id(p) for p in pos_embeds)
+        hit = tables.get(key) if self.no_padding else None
+        if hit is not None and all(r() is p for r, p in zip(hit[0], pos_embeds)):
+            cat = hit[1]
+        else:
+            cat = torch.cat([p.flatten(2).transpose(1, 2) for p in pos_embeds], 1).contiguous()
+            if self.no_padding:
+                if len(tables) >= 8:
+                    tables.clear()
+                tables[key] = (tuple(weakref.ref(p) for p in pos_embeds), cat)
+        sizes = [int(p.shape[2] * p.shape[3]) for p in pos_embeds]
+        return _AddLevelEmbed.apply(cat, self.level_embed, sizes)
+
     def encode(self, srcs, masks, pos_embeds):
         """Flatten the pyramid and run the deformable encoder.  Every encoder operation is
         per-sample, so the source and target halves of a DATR batch can share one call."""
@@ -555,13 +612,10 @@ class DeformableTransformer(nn.Module):
             shapes_list.append((h, w))
             src_flatten.append(src.flatten(2).transpose(1, 2))
             mask_flatten.append(mask.flatten(1))
-            pos_embed = pos_embed.flatten(2).transpose(1, 2)
-            if self.num_feature_levels > 1 and self.level_embed is not None:
-                pos_embed = pos_embed + self.level_embed[lvl].view(1, 1, -1)
             lvl_pos_embed_flatten.append(pos_embed)
         src_flatten = torch.cat(src_flatten, 1)
         mask_flatten = torch.cat(mask_flatten, 1)
-        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+        lvl_pos_embed_flatten = self._level_positions(lvl_pos_embed_flatten)
         spatial_shapes, level_start_index = self._level_meta(shapes_list, src_flatten.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         memory, _, _ = self.encoder(src_flatten, pos=lvl_pos_embed_flatten,

@@ -442,3 +442,33 @@ def test_plain_layer_norm_through_the_fused_kernel_matches_autograd():
     torch.testing.assert_close(layer_norm(x, ln), y_ref, rtol=1e-5, atol=1e-5)
     for a, b in zip(got, ref):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())))
+
+
+def test_level_embedding_add_matches_the_per_level_formula():
+    """transformer._level_positions (one cat, one broadcast add, column-sum backward) against the
+    reference's per-level `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` and cat
+    (deformable_transformer.py:283-286): identical values, level_embed gradient to float32 rounding;
+    the flattened table is reused only for the very same embedding tensors."""
+    from datr_amd import transformer as T
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    from tests.helpers import build_model
+    tr = build_model()[1].transformer.to(dev)
+    sizes = [(13, 21), (7, 11), (4, 6), (2, 3)]
+    pos = [torch.randn(3, 256, h, w, device=dev) for h, w in sizes]
+    go = torch.randn(3, sum(h * w for h, w in sizes), 256, device=dev)
+    for no_padding in (True, False):
+        tr.no_padding = no_padding
+        out = tr._level_positions(pos)
+        ref = torch.cat([p.flatten(2).transpose(1, 2) + tr.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos)], 1)
+        assert torch.equal(out, ref)
+        (g,) = torch.autograd.grad(out, tr.level_embed, go)
+        (gr,) = torch.autograd.grad(ref, tr.level_embed, go)
+        torch.testing.assert_close(g, gr, rtol=1e-5, atol=1e-4)
+    tr.no_padding = True
+    a = tr._level_positions(pos)
+    pos2 = [p.clone() + 1 for p in pos]
+    b = tr._level_positions(pos2)                                   # other tensors: no stale table
+    assert torch.equal(b, torch.cat([p.flatten(2).transpose(1, 2) + tr.level_embed[l].view(1, 1, -1)
+                                     for l, p in enumerate(pos2)], 1))
+    assert torch.equal(tr._level_positions(pos), a)
