@@ -421,8 +421,7 @@ class _AddLevelEmbed(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, level_embed, sizes):
         ctx.sizes = sizes
-        rows = torch.repeat_interleave(level_embed[:len(sizes)],
-                                       torch.tensor(sizes, device=level_embed.device), dim=0, output_size=sum(sizes))
+        rows = torch.cat([level_embed[l].expand(n, -1) for l, n in enumerate(sizes)], 0)   # no host -> device copy
         return pos + rows.unsqueeze(0)
 
     @staticmethod
