@@ -75,6 +75,8 @@ def broadcast_module_state(module: nn.Module, src: int = 0, group=None):
 
 
 class _Bucket:
+    ALIGN = 64       # elements
+
     def view(self, p: nn.Parameter, offset: int) -> torch.Tensor:
         """The slice of the flat buffer that is `p`'s gradient, with `p`'s own strides: a
         channels_last conv weight gets a channels_last gradient view (fused AdamW requires
@@ -89,13 +91,20 @@ class _Bucket:
     def __init__(self, params: List[nn.Parameter], device, dtype, side: bool = False):
         self.params = params
         self.side = side
-        self.numel = sum(p.numel() for p in params)
+        # every slice starts on a 256-byte boundary: the multi-tensor kernels that read the gradient
+        # views (fused AdamW, the clip's norm, the copy-in) take their 16-byte vector path only for
+        # aligned pointers -- packed back to back, everything behind the first odd-sized tensor (a
+        # [4] or [9] bias) was misaligned and AdamW ran 0.96 instead of 0.51 ms per step.  The
+        # padding stays zero and travels through the all-reduce.
+        offsets, offset = [], 0
+        for p in params:
+            offsets.append(offset)
+            offset = (offset + p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = offset
         self.flat = torch.zeros(self.numel, device=device, dtype=dtype)
         self.views = []
-        offset = 0
-        for p in params:
-            self.views.append(self.view(p, offset))
-            offset += p.numel()
+        for p, off in zip(params, offsets):
+            self.views.append(self.view(p, off))
             p.grad = None
         self.pending = len(params)
         self.work = None
