@@ -59,6 +59,7 @@ _SIGNATURES = {
     "datr_resize_bilinear_u8": [_vp, _i64, _i64, ctypes.c_int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp,
                                 _vp, _vp],
     "datr_conv3x3_wino_wgrad_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+    "datr_zero_rows_f32": [_vp, _vp, _i64, _i64, _vp],
     "datr_ema_update_f32": [_vp, _vp, _i64, ctypes.c_double, _vp],
     "datr_pixel_ops_u8": [_vp, _vp, _i64, _vp, _i64, _vp, _vp],
     "datr_box_blur_u8": [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint32, ctypes.c_uint32, _i64, _vp],

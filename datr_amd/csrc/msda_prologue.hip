@@ -141,3 +141,27 @@ extern "C" int datr_msda_prologue_backward_f32(const float *d_loc, const float *
         hipLaunchKernelGGL(prologue_bwd<4>, grid, dim3(256), 0, (hipStream_t)stream, d_loc, d_attn, attn, ref, (long)rows, d_both);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
+
+// `value.masked_fill(input_padding_mask[..., None], 0)` (ms_deform_attn.py:101-102) and its backward,
+// in place: only the rows of padded tokens are touched (one mask byte read per 16 output bytes, a
+// store for masked rows only) instead of a read + write pass over the whole [N, S, C] tensor.
+namespace {
+__global__ __launch_bounds__(256) void zero_rows_kernel(float4 *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                        long rows, int cols4)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols4) return;
+    if (mask[i / cols4]) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+
+extern "C" int datr_zero_rows_f32(float *x, const uint8_t *mask, int64_t rows, int64_t cols, void *stream) {
+    if (rows < 0 || cols <= 0 || (cols & 3)) return DATR_EINVAL;
+    if (rows == 0) return DATR_OK;
+    if (!x || !mask || ((uintptr_t)x & 15)) return DATR_EINVAL;
+    const int64_t n = rows * (cols / 4);
+    if (n > 0x7fffffffLL * 256) return DATR_EUNSUPPORTED;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4 *>(x), mask, (long)rows, (int)(cols / 4));
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}

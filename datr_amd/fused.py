@@ -354,10 +354,13 @@ class _LinearFn(Function):
     def forward(ctx, x, w, b):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        y = torch.addmm(b, x2, w.t())
+        # the result is allocated in its final shape (the GEMM writes through a 2-d view of it): the
+        # caller gets a tensor that is nobody's view and may hand it to an in-place op (msda._ZeroRows)
+        out = torch.empty(*shape[:-1], w.shape[0], device=x.device, dtype=x.dtype)
+        torch.addmm(b, x2, w.t(), out=out.view(-1, w.shape[0]))
         ctx.save_for_backward(x2, w)
         ctx.shape = shape
-        return y.view(*shape[:-1], w.shape[0])
+        return out
 
     @staticmethod
     @once_differentiable

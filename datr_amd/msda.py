@@ -318,6 +318,46 @@ _MONITORS = weakref.WeakKeyDictionary()            # module -> OffsetMonitor (no
 ADAPTIVE_ROUTING = __import__("os").environ.get("DATR_MSDA_ADAPTIVE", "1") != "0"
 
 
+class _ZeroRows(torch.autograd.Function):
+    """x.masked_fill(mask[..., None], 0) in place on a tensor nobody else reads (the fresh output of
+    value_proj); the gradient gets the same treatment.  csrc/msda_prologue.hip::zero_rows_kernel."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        ctx.mark_dirty(x)
+        _zero_rows_(x, mask)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        g = g.contiguous()
+        if not g.is_cuda or g.dtype != torch.float32:
+            return g.masked_fill(mask[..., None], 0.0), None
+        g = g.clone() if g._base is not None else g       # never write into somebody's view
+        _zero_rows_(g, mask)
+        return g, None
+
+
+def _zero_rows_(x, mask):
+    m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+    with torch.cuda.device(x.device):
+        rc = _native.lib.datr_zero_rows_f32(x.data_ptr(), m.contiguous().data_ptr(), m.numel(), x.shape[-1],
+                                            _native.current_stream_ptr(x.device))
+    _native.check(rc, "zero_rows")
+
+
+def zero_padded_rows(value, mask):
+    """`value.masked_fill(mask[..., None], 0.0)` (ms_deform_attn.py:101-102); on the device, for the
+    contiguous fp32 output of value_proj, in place and touching only the padded rows."""
+    if (value.is_cuda and value.dtype == torch.float32 and value.is_contiguous() and value.shape[-1] % 4 == 0
+            and mask.is_cuda and mask.shape == value.shape[:-1] and value._base is None
+            and (not value.requires_grad or not value.is_leaf)):
+        return _ZeroRows.apply(value, mask)
+    return value.masked_fill(mask[..., None], 0.0)
+
+
 class MSDeformAttn(nn.Module):
     """Same constructor, parameter names (state_dict keys `sampling_offsets`,
     `attention_weights`, `value_proj`, `output_proj`), initialisation and forward signature as
@@ -365,7 +405,7 @@ class MSDeformAttn(nn.Module):
         H = self.n_heads
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+            value = zero_padded_rows(value, input_padding_mask)
         value = value.view(N, Len_in, H, self.d_model // H)
         fold_wh = False
         if query.is_cuda and MERGE_QUERY_PROJECTIONS:

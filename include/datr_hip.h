@@ -253,6 +253,12 @@ int datr_resize_bilinear_u8(const uint8_t *src, int64_t H, int64_t W, int flip, 
                             const int32_t *xk, int64_t ksx, const int32_t *ybounds, const int32_t *yk,
                             int64_t ksy, int64_t oh, int64_t ow, uint8_t *tmp, uint8_t *dst, void *stream);
 
+/* `value.masked_fill(input_padding_mask[..., None], 0)` of MSDeformAttn
+ * (/root/reference/models/dino/ops/modules/ms_deform_attn.py:101-102) IN PLACE on x [rows, cols]
+ * (cols % 4 == 0, x 16-byte aligned): rows whose mask byte is non-zero are zeroed, the others are
+ * not touched.  The backward of that op is the same call on the gradient. */
+int datr_zero_rows_f32(float *x, const uint8_t *mask, int64_t rows, int64_t cols, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * EMA teacher update, all tensors in one launch (csrc/ema.hip): the reference's key walk
  * `v *= d; v += (1. - d) * msd[k]` (/root/reference/models/dino/EMA.py:46-50, :123-128).

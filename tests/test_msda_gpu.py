@@ -436,3 +436,46 @@ def test_routes_agree_and_the_offset_monitor_switches_them():
     assert mon.fraction > 0.5 and mon.route == msda.OffsetMonitor.route_for(mon.fraction) and mon.route > 0
     torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-4)      # route 0 vs the new route: same values
     assert y0.shape == y1.shape
+
+
+def test_padded_rows_are_zeroed_in_place_like_masked_fill():
+    """MSDeformAttn with a padding mask: `value.masked_fill(mask[..., None], 0)`
+    (ms_deform_attn.py:101-102) done by the in-place row kernel (and again on the gradient) gives the
+    module output and every gradient of the masked_fill formulation."""
+    from datr_amd import msda
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes = [(12, 17), (6, 9), (3, 5), (2, 3)]
+    S = sum(h * w for h, w in shapes)
+    attn = msda.MSDeformAttn(256, 4, 8, 4).to(dev)
+    with torch.no_grad():
+        attn.sampling_offsets.weight.normal_(0, 0.02)
+        attn.attention_weights.weight.normal_(0, 0.02)
+    src = torch.randn(2, S, 256, device=dev, requires_grad=True)
+    ref = torch.rand(2, S, 4, 2, device=dev)
+    mask = torch.rand(2, S, device=dev) < 0.3
+    ss = torch.tensor(shapes, device=dev)
+    lsi = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
+    go = torch.randn(2, S, 256, device=dev)
+    params = list(attn.parameters())
+    calls = []
+    real = msda._zero_rows_
+    msda._zero_rows_ = lambda x, m: (calls.append(1), real(x, m))[1]
+    try:
+        own = torch.autograd.grad(attn(src, ref, src, ss, lsi, mask), [src] + params, go)
+    finally:
+        msda._zero_rows_ = real
+    assert len(calls) == 2                                          # forward and backward
+    saved = msda.zero_padded_rows
+    msda.zero_padded_rows = lambda v, m: v.masked_fill(m[..., None], 0.0)
+    try:
+        lib = torch.autograd.grad(attn(src, ref, src, ss, lsi, mask), [src] + params, go)
+    finally:
+        msda.zero_padded_rows = saved
+    for a, b in zip(own, lib):                   # (the row kernel's float atomics are not order-stable: no bitwise claim)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+    # the op itself, bit for bit, on a tensor of its own
+    v = torch.randn(2, S, 256, device=dev)
+    want = v.masked_fill(mask[..., None], 0.0)
+    got = msda.zero_padded_rows(v.clone().requires_grad_(True) * 1.0, mask)
+    assert torch.equal(got, want)
