@@ -335,7 +335,8 @@ class _ZeroRows(torch.autograd.Function):
         g = g.contiguous()
         if not g.is_cuda or g.dtype != torch.float32:
             return g.masked_fill(mask[..., None], 0.0), None
-        g = g.clone() if g._base is not None else g       # never write into somebody's view
+        # g is this node's own incoming gradient (the buffer MSDA's backward produced, handed over
+        # through a reshape): nobody reads it after this node, so it is zeroed where it lies
         _zero_rows_(g, mask)
         return g, None
 
