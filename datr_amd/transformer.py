@@ -412,6 +412,8 @@ class TransformerDecoder(nn.Module):
                 [r.transpose(0, 1) for r in ref_points]]
 
 
+# DATR_SELECTED_ROWS_BWD=0: differentiate enc_output over all encoder tokens, as the reference does
+SELECTED_ROWS_BACKWARD = __import__("os").environ.get("DATR_SELECTED_ROWS_BWD", "1") != "0"
 _POS_TABLES = {}          # ids of the per-level position embeddings -> (weak refs, flattened [N, S, C] table)
 
 
@@ -643,18 +645,41 @@ class DeformableTransformer(nn.Module):
 
         if self.two_stage_type == "standard":
             input_hw = self.two_stage_wh_embedding.weight[0] if self.two_stage_learn_wh else None
-            output_memory, output_proposals = gen_encoder_output_proposals(
-                memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding)
-            output_memory = layer_norm(self.enc_output(output_memory), self.enc_output_norm)
-            enc_class = self.enc_out_class_embed(output_memory)
-            enc_coord = self.enc_out_bbox_embed(output_memory) + output_proposals   # logits
-            topk_idx = self.select_queries(enc_class.max(-1)[0])
-            refpoint_embed_undetach = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
+            # Only the selected 900 tokens per image carry gradient back into enc_output / its norm: the
+            # class scores of all tokens feed the (non-differentiable) top-k and nothing else reads the
+            # unselected rows (deformable_transformer.py:338-350).  On the device, in training, the pass
+            # over ALL tokens therefore runs without autograd, and the selected rows are projected and
+            # normalised again WITH autograd -- 3 600 rows instead of 88 892 through the backward of the
+            # projection (weight gradient, data gradient), the LayerNorm and the masking.  Same values
+            # up to the GEMM's rounding for a different row count; the host path keeps the reference's order.
+            sparse = (memory.is_cuda and torch.is_grad_enabled() and memory.requires_grad and input_hw is None
+                      and SELECTED_ROWS_BACKWARD)
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not sparse):
+                output_memory, output_proposals = gen_encoder_output_proposals(
+                    memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding)
+                output_memory = layer_norm(self.enc_output(output_memory), self.enc_output_norm)
+                enc_class = self.enc_out_class_embed(output_memory)
+                topk_idx = self.select_queries(enc_class.max(-1)[0])
+            selected_proposals = torch.gather(output_proposals, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
+            if sparse:
+                rows = torch.gather(memory, 1, topk_idx.unsqueeze(-1).repeat(1, 1, self.d_model))
+                rows = rows.masked_fill(torch.isinf(selected_proposals[..., :1]), 0.0)     # invalid anchors
+                tgt_undetach = layer_norm(self.enc_output(rows), self.enc_output_norm)
+            else:
+                tgt_undetach = torch.gather(output_memory, 1,
+                                            topk_idx.unsqueeze(-1).repeat(1, 1, self.d_model))
+            if output_memory.is_cuda:
+                # The reference runs the box head on ALL tokens and gathers the selected 900 per image
+                # (deformable_transformer.py:339-343); the head is a per-token MLP and nothing else reads
+                # the unselected rows, so on the device it runs on the gathered rows only: 3 600 instead
+                # of 88 892 rows through three layers, forward and backward (same values up to the
+                # GEMM's rounding for a different row count; the host path keeps the reference's order).
+                refpoint_embed_undetach = self.enc_out_bbox_embed(tgt_undetach) + selected_proposals   # logits
+            else:
+                enc_coord = self.enc_out_bbox_embed(output_memory) + output_proposals
+                refpoint_embed_undetach = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
             refpoint_embed_ = refpoint_embed_undetach.detach()
-            init_box_proposal = torch.gather(
-                output_proposals, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4)).sigmoid()
-            tgt_undetach = torch.gather(output_memory, 1,
-                                        topk_idx.unsqueeze(-1).repeat(1, 1, self.d_model))
+            init_box_proposal = selected_proposals.sigmoid()
             if self.embed_init_tgt:
                 tgt_ = self.tgt_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
             else:
