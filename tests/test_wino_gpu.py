@@ -270,3 +270,27 @@ def test_wino_wgrad_refuses_other_channel_counts():
     x = torch.zeros(1, 64, 8, 8, device="cuda:0").contiguous(memory_format=torch.channels_last)
     dy = torch.zeros(1, 48, 8, 8, device="cuda:0").contiguous(memory_format=torch.channels_last)
     assert wino_wgrad([x], [dy], w) is None
+
+
+def test_wino_wgrad_full_size_pyramid_against_the_library():
+    """The shape the training step runs: 256 -> 128 over the four pyramid levels of four images at
+    1333x800 (one split-K launch, segments crossing level boundaries) against the library's
+    weight-gradient convolution summed over the levels, and linearity in dY (a size-independent
+    property: wgrad(x, a dy1 + dy2) = a wgrad(x, dy1) + wgrad(x, dy2))."""
+    from datr_amd.wino import wino_wgrad
+    g = torch.Generator().manual_seed(9)
+    sizes = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    w = torch.randn(128, 256, 3, 3, generator=g).to("cuda:0")
+    xs = [_cl(torch.randn(4, 256, h, ww, generator=g).to("cuda:0")) for h, ww in sizes]
+    d1 = [_cl(torch.randn(4, 128, h, ww, generator=g).to("cuda:0")) for h, ww in sizes]
+    d2 = [_cl(torch.randn(4, 128, h, ww, generator=g).to("cuda:0")) for h, ww in sizes]
+    got = wino_wgrad(xs, d1, w)
+    lib = None
+    for x, dy in zip(xs, d1):
+        _, gw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                       [False, True, False])
+        lib = gw if lib is None else lib + gw
+    scale = float(lib.abs().max())
+    assert float((got - lib).abs().max()) <= 2e-5 * scale
+    mix = wino_wgrad(xs, [0.5 * a + b for a, b in zip(d1, d2)], w)
+    assert float((mix - (0.5 * got + wino_wgrad(xs, d2, w))).abs().max()) <= 2e-5 * scale
