@@ -13,14 +13,19 @@
 // tiles (split-K; the tiles of all pyramid levels, in chunks of 8, form one index space that is cut
 // into equal segments, ~one workgroup per CU in flight) and writes its partial sums; `wino_wgrad_fold` adds the segments in a fixed order
 // (deterministic, unlike an atomic accumulation) and applies G^T . G.
-// Tiles go by in chunks of 8, double-buffered in LDS with one barrier per chunk: waves 0-3 fetch the
-// 4x4 input patches of the next chunk (thread = tile x 4 channels x two of the four transform rows),
-// waves 4-7 the 2x2 dY tiles (raw buffer loads, out-of-image pixels read as zero), transform what they
-// fetched and write it into the operand layout [pos][row][8 tiles], in which an MFMA lane reads the four k-steps of a
-// chunk with ONE ds_read_b128 (k-step j pairs tile j with tile j + 4).  LDS rows are channels in the
-// order row = 16 (c % 4) + c / 4, and the two 4-tile halves of a row are swapped when bit 3 of the
-// row is set: writes (b32) and reads (b128) are then bank-conflict free.  The partial sums keep that
-// row order; the fold kernel undoes it.
+// Tiles go by in chunks of 8, double-buffered in LDS with one barrier per chunk.  Every thread has
+// the same role: wave = tile of the chunk, lane = (4 channels, patch row r): it fetches row r of the
+// tile's 4x4 input patch (4 buffer_load_b128) and one pixel of its 2x2 dY tile (raw buffer loads,
+// out-of-image pixels read as zero), for TWO chunks ahead (two register sets; every call issues the
+// same number of loads, so the compiler waits with vmcnt(5) for the older chunk only).  The four rows
+// of a patch sit in the four lanes of a quad: the row transforms B^T d and A dY are one DPP quad_perm
+// plus a per-lane +-1 combination, the thread then owns transform row xi = r, finishes the column
+// transform in registers and writes its 4 positions x 4 channels of both operands into the layout
+// [pos][row][8 tiles], in which an MFMA lane reads the four k-steps of a chunk with ONE ds_read_b128
+// (k-step j pairs the j-th tile of the lower half with the j-th of the upper).  LDS rows are channels
+// in the order row = 16 (c % 4) + c / 4, the two 4-tile halves of a row are swapped when bit 3 of the
+// row is set and the tiles of a half are rotated by xi: the b32 writes of a wave and the b128 reads
+// are bank-conflict free.  The partial sums keep that row order; the fold kernel undoes it.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -54,6 +59,18 @@ struct Args {
     int nlevels, chunks, nseg, N, Cin, Cout;
 };
 
+// quad_perm DPP: lane r of every quad reads lane S_r of the same quad
+template <int S0, int S1, int S2, int S3>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v),
+                                                                 S0 | (S1 << 2) | (S2 << 4) | (S3 << 6), 0xF, 0xF, true));
+}
+template <int S0, int S1, int S2, int S3>
+__device__ __forceinline__ float4 quad_perm(float4 v) {
+    return make_float4(quad_perm<S0, S1, S2, S3>(v.x), quad_perm<S0, S1, S2, S3>(v.y), quad_perm<S0, S1, S2, S3>(v.z),
+                       quad_perm<S0, S1, S2, S3>(v.w));
+}
+
 __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -69,20 +86,25 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
     const int cbeg = (int)((long long)args.chunks * blockIdx.z / args.nseg);
     const int cend = (int)((long long)args.chunks * (blockIdx.z + 1) / args.nseg);
 
-    // ---- fetch role: thread = (tile ft, channel quad fq, half fh of the transform rows); waves 0-3 take
-    // the input patches (is_x), waves 4-7 the dY tiles
-    const bool is_x = wave < 4;
-    const int ft = tid & 7, fq = (tid >> 3) & 15, fh = (tid >> 7) & 1;
+    // ---- fetch / transform role (every thread): tile ft = the wave, channel quad fq, patch row fr.
+    // The four rows of a patch sit in the four lanes of a quad, so the row transform B^T d (and A dY)
+    // is one DPP exchange inside the quad; the thread then owns transform row xi = fr.
+    const int ft = wave, fq = lane >> 2, fr = lane & 3;
     const unsigned xchan = (unsigned)((ci0 + fq * 4) * 4), ychan = (unsigned)((co0 + fq * 4) * 4);
     int lvl = -1, H = 0, W = 0, TH = 0, TW = 0, ltiles = 0, lend = 0;     // current level (uniform)
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(args.lv[0].x), 0, 0, 0x00020000);
     __amdgpu_buffer_rsrc_t ry = rx;
     int fc = cbeg;                                 // chunk the next fetch() reads
-    int tt = 0, tx = 0, ty = 0, tn = 0;            // this thread's tile of that chunk
-    float4 rawx[12], rawy[4];                      // fetched input patch rows (waves 0-3) / dY tile (waves 4-7)
+    int tt = 0, tx = 0, ty = 0, tn = 0;            // this WAVE's tile of that chunk
 
-    auto fetch = [&](auto role_x) {
-        if (fc >= lend) {                          // (first call, or) the chunk opens the next level
+    struct Raw { float4 x[4]; float4 y; };        // patch row fr (4 columns) and dY pixel (fr >> 1, fr & 1)
+    auto fetch = [&](Raw &raw) {
+        // Called unconditionally, also past the segment's (and the chunk space's) end -- the loads then
+        // carry out-of-range offsets and return zeros: with a fixed number of loads per call the compiler
+        // can wait for the OLDER chunk's five loads only (vmcnt(5)); a conditional fetch made it wait for
+        // everything in flight, i.e. for the loads it had just issued.
+        const bool past = fc >= args.chunks;
+        if (!past && fc >= lend) {                 // (first call, or) the chunk opens the next level
             do { ++lvl; lend = (lvl + 1 < args.nlevels) ? args.lv[lvl + 1].first : args.chunks; } while (fc >= lend);
             const Level L = args.lv[lvl];
             H = L.H; W = L.W; TH = L.TH; TW = L.TW; ltiles = L.tiles;
@@ -91,94 +113,73 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
             tt = (fc - L.first) * TK + ft;
             tx = tt % TW; ty = (tt / TW) % TH; tn = tt / (TW * TH);
         }
-        const bool live = tt < ltiles;
-        if constexpr (decltype(role_x)::value) {
-            const int y0 = 2 * ty - 1 + fh, x0 = 2 * tx - 1;           // rows y0 .. y0 + 2, columns x0 .. x0 + 3
-            unsigned coff[4];
+        const bool live = !past && tt < ltiles;
+        {
+            const int y = 2 * ty - 1 + fr, x0 = 2 * tx - 1;
+            const bool rv = live && y >= 0 && y < H;
+            const unsigned roff = (unsigned)((tn * H + y) * W + x0) * (unsigned)(Cin * 4) + xchan;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) coff[b] = (x0 + b >= 0 && x0 + b < W) ? (unsigned)((x0 + b) * Cin * 4) + xchan : kOOB;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int y = y0 + a;
-                const bool rv = live && y >= 0 && y < H;
-                const unsigned roff = (unsigned)((tn * H + y) * W) * (unsigned)(Cin * 4);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const unsigned off = (rv && coff[b] != kOOB) ? roff + coff[b] : kOOB;
-                    rawx[a * 4 + b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-                }
+            for (int b = 0; b < 4; ++b) {
+                const unsigned off = (rv && x0 + b >= 0 && x0 + b < W) ? roff + (unsigned)(b * Cin * 4) : kOOB;
+                raw.x[b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
             }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int y = 2 * ty + a, x = 2 * tx + b;
-                    const unsigned off = (live && y < H && x < W)
-                        ? (unsigned)(((tn * H + y) * W + x)) * (unsigned)(Cout * 4) + ychan : kOOB;
-                    rawy[a * 2 + b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
-                }
         }
-        // the same thread's tile of the next chunk
+        {
+            const int y = 2 * ty + (fr >> 1), x = 2 * tx + (fr & 1);
+            const unsigned off = (live && y < H && x < W)
+                ? (unsigned)((tn * H + y) * W + x) * (unsigned)(Cout * 4) + ychan : kOOB;
+            raw.y = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
+        }
+        // the wave's tile of the next chunk
         ++fc; tt += TK; tx += TK;
         while (tx >= TW) { tx -= TW; if (++ty == TH) { ty = 0; ++tn; } }
     };
 
-    // LDS float index of (pos, row, tile): halves swapped on bit 3 of the row
-    const int frow_sw = (fq >> 3) & 1;
-    const int fslot = (((ft >> 2) ^ frow_sw) << 2) + (ft & 3);
-    auto put = [&](float *buf, int pos, float4 v) {             // channels 4 fq + e -> rows 16 e + fq
-        float *p = buf + (pos * BC + fq) * TK + fslot;
+    // LDS float index of (pos, row, tile): halves swapped on bit 3 of the row, tiles rotated inside their
+    // half by the transform row xi (= fr for the writer): the four lanes of a quad then hit four banks,
+    // and both operands of a position are rotated alike, so the MFMA's k pairing is unaffected
+    const int fslot = (((ft >> 2) ^ ((fq >> 3) & 1)) << 2) + ((ft + fr) & 3);
+    auto put = [&](float *buf, int nu, float4 v) {              // pos = 4 fr + nu; channels 4 fq + e -> rows 16 e + fq
+        float *p = buf + ((fr * 4 + nu) * BC + fq) * TK + fslot;
         p[0 * 16 * TK] = v.x; p[1 * 16 * TK] = v.y; p[2 * 16 * TK] = v.z; p[3 * 16 * TK] = v.w;
     };
     auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
     auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
     auto neg = [](float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); };
+    auto lin = [](float p, float4 a, float q, float4 b) {       // p a + q b
+        return make_float4(fmaf(q, b.x, p * a.x), fmaf(q, b.y, p * a.y), fmaf(q, b.z, p * a.z), fmaf(q, b.w, p * a.w));
+    };
+    // B^T rows: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 = p * (own row) + q * (row of lane 2, 2, 1, 1)
+    const float xp = fr == 3 ? -1.f : 1.f, xq = (fr == 1 || fr == 3) ? 1.f : -1.f;
+    // A rows on the dY tile: xi 0: y0, 1: y0 + y1, 2: y0 - y1, 3: -y1 = p * y0 + q * y1
+    const float yp = fr == 3 ? 0.f : 1.f, yq = fr == 0 ? 0.f : fr == 1 ? 1.f : -1.f;
 
-    // the transform of the fetched chunk -> operand buffer `buf`
-    auto transform = [&](int buf, auto role_x) {
-        if constexpr (decltype(role_x)::value) {
-            // rows fetched: patch rows fh .. fh + 2.  B^T rows: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    auto transform = [&](int buf, const Raw &raw) {
+        {
+            float4 R[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) R[b] = lin(xp, raw.x[b], xq, quad_perm<2, 2, 1, 1>(raw.x[b]));
             float *dst = Vs + buf * kOpF;
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const int xi = 2 * fh + x;
-                float4 R[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float4 r0 = rawx[0 * 4 + b], r1 = rawx[1 * 4 + b], r2 = rawx[2 * 4 + b];
-                    if (fh == 0) R[b] = (x == 0) ? sub(r0, r2) : add(r1, r2);
-                    else         R[b] = (x == 0) ? sub(r1, r0) : sub(r0, r2);
-                }
-                put(dst, xi * 4 + 0, sub(R[0], R[2]));
-                put(dst, xi * 4 + 1, add(R[1], R[2]));
-                put(dst, xi * 4 + 2, sub(R[2], R[1]));
-                put(dst, xi * 4 + 3, sub(R[1], R[3]));
-            }
-        } else {
-            // A rows: xi 0: y0, 1: y0 + y1, 2: y0 - y1, 3: -y1  (rows of the 2x2 dY tile), same on columns
+            put(dst, 0, sub(R[0], R[2]));
+            put(dst, 1, add(R[1], R[2]));
+            put(dst, 2, sub(R[2], R[1]));
+            put(dst, 3, sub(R[1], R[3]));
+        }
+        {
+            // the quad holds dY[0][0], [0][1], [1][0], [1][1] in lanes 0..3
+            const float4 d00 = quad_perm<0, 0, 0, 0>(raw.y), d01 = quad_perm<1, 1, 1, 1>(raw.y);
+            const float4 d10 = quad_perm<2, 2, 2, 2>(raw.y), d11 = quad_perm<3, 3, 3, 3>(raw.y);
+            const float4 S0 = lin(yp, d00, yq, d10), S1 = lin(yp, d01, yq, d11);
             float *dst = Us + buf * kOpF;
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const int xi = 2 * fh + x;
-                float4 S[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float4 y0 = rawy[b], y1 = rawy[2 + b];
-                    if (fh == 0) S[b] = (x == 0) ? y0 : add(y0, y1);
-                    else         S[b] = (x == 0) ? sub(y0, y1) : neg(y1);
-                }
-                put(dst, xi * 4 + 0, S[0]);
-                put(dst, xi * 4 + 1, add(S[0], S[1]));
-                put(dst, xi * 4 + 2, sub(S[0], S[1]));
-                put(dst, xi * 4 + 3, neg(S[1]));
-            }
+            put(dst, 0, S0);
+            put(dst, 1, add(S0, S1));
+            put(dst, 2, sub(S0, S1));
+            put(dst, 3, neg(S1));
         }
     };
 
     // ---- multiply role: wave w owns positions 2 w, 2 w + 1 (128 accumulator registers) ----------------
-    // (not zero-initialised: 256 zeros alive through the prologue would sit in ordinary registers and
-    // spill the fetch; the first chunk's first k-step multiplies onto the inline constant 0 instead)
+    // (not zero-initialised: the first chunk's first k-step multiplies onto the inline constant 0)
     f32x16 acc[PW][2][2];
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int rslot = (lhi ^ ((l31 >> 3) & 1)) << 2;
@@ -205,38 +206,26 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
                             (decltype(first)::value && k == 0) ? zero : acc[p][i][j], 0, 0, 0);
     };
 
-    // Waves w and w + 4 share a SIMD, and every wave multiplies chunk c at the top of iteration c (the
-    // accumulators never sit in role-dependent control flow).  The dY waves then transform chunk c + 1
-    // BEFORE the closing barrier; the patch waves (the heavier transform) do theirs AFTER it, for chunk
-    // c + 2, while the dY wave of the same SIMD is already multiplying: the MFMA pipe is fed by one wave
-    // while the other does its VALU / LDS work.  Each fetch is issued right after the transform that
-    // frees its registers and has a whole multiply phase to land.
+    // Two chunks of raw data in flight: iteration c issues the loads of chunk c + 2 into the registers
+    // chunk c freed, multiplies chunk c and then transforms chunk c + 1 (fetched one iteration earlier:
+    // the loads have two multiply phases to land).  One barrier per chunk.
     const int nchunks = cend - cbeg;               // >= 1: the host never makes more segments than chunks
-    const std::true_type X{};
-    const std::false_type Y{};
-    if (is_x) {
-        fetch(X); transform(0, X);
-        if (nchunks > 1) { fetch(X); transform(1, X); }
-        if (nchunks > 2) fetch(X);
-    } else {
-        fetch(Y); transform(0, Y);
-        if (nchunks > 1) fetch(Y);
-    }
+    Raw r0, r1;
+    fetch(r0);
+    transform(0, r0);
+    fetch(r1);
     __syncthreads();
-    auto iteration = [&](int c, auto first) {
+    auto iteration = [&](int c, Raw &mine, Raw &other, auto first) {   // `mine`: chunk c's registers (free), `other`: chunk c + 1
+        if (!(WGRAD_ABLATE & 1)) fetch(mine);
         if (!(WGRAD_ABLATE & 4) || decltype(first)::value) multiply(c & 1, first);
-        if (!is_x) {
-            if (!(WGRAD_ABLATE & 2) && c + 1 < nchunks) transform((c + 1) & 1, Y);
-            if (!(WGRAD_ABLATE & (1 | 32)) && c + 2 < nchunks) fetch(Y);
-        }
+        if (!(WGRAD_ABLATE & 2) && c + 1 < nchunks) transform((c + 1) & 1, other);
         if (!(WGRAD_ABLATE & 8)) __syncthreads();
-        if (is_x) {
-            if (!(WGRAD_ABLATE & 2) && c + 2 < nchunks) transform(c & 1, X);
-            if (!(WGRAD_ABLATE & (1 | 16)) && c + 3 < nchunks) fetch(X);
-        }
     };
-    iteration(0, std::true_type{});
-    for (int c = 1; c < nchunks; ++c) iteration(c, std::false_type{});
+    iteration(0, r0, r1, std::true_type{});
+    for (int c = 1; c < nchunks; c += 2) {
+        iteration(c, r1, r0, std::false_type{});
+        if (c + 1 < nchunks) iteration(c + 1, r0, r1, std::false_type{});
+    }
 
     // ---- partial[segment][pos][cout row][cin row], rows in LDS order within each 64-block -----------
     float *out = partial + (size_t)blockIdx.z * 16 * Cout * Cin;
