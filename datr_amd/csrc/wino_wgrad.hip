@@ -41,6 +41,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 512;                   // 8 waves, two per SIMD: 128 accumulator + <= 128 other registers each
 constexpr int PW = 2;                           // positions per wave
@@ -139,26 +140,31 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
     // half by the transform row xi (= fr for the writer): the four lanes of a quad then hit four banks,
     // and both operands of a position are rotated alike, so the MFMA's k pairing is unaffected
     const int fslot = (((ft >> 2) ^ ((fq >> 3) & 1)) << 2) + ((ft + fr) & 3);
-    auto put = [&](float *buf, int nu, float4 v) {              // pos = 4 fr + nu; channels 4 fq + e -> rows 16 e + fq
+    // Packed arithmetic (v_pk_add_f32 / v_pk_fma_f32: two floats per instruction) on the float4s.
+    struct P4 { f32x2 lo, hi; };
+    auto pk = [](float4 v) { return P4{f32x2{v.x, v.y}, f32x2{v.z, v.w}}; };
+    auto sub = [](P4 a, P4 b) { return P4{a.lo - b.lo, a.hi - b.hi}; };
+    auto add = [](P4 a, P4 b) { return P4{a.lo + b.lo, a.hi + b.hi}; };
+    auto fma2 = [](float q, P4 b, P4 a) {                       // a + q b
+        const f32x2 qq = {q, q};
+        return P4{__builtin_elementwise_fma(qq, b.lo, a.lo), __builtin_elementwise_fma(qq, b.hi, a.hi)};
+    };
+    auto put = [&](float *buf, int nu, P4 v) {                  // pos = 4 fr + nu; channels 4 fq + e -> rows 16 e + fq
         float *p = buf + ((fr * 4 + nu) * BC + fq) * TK + fslot;
-        p[0 * 16 * TK] = v.x; p[1 * 16 * TK] = v.y; p[2 * 16 * TK] = v.z; p[3 * 16 * TK] = v.w;
+        p[0 * 16 * TK] = v.lo.x; p[1 * 16 * TK] = v.lo.y; p[2 * 16 * TK] = v.hi.x; p[3 * 16 * TK] = v.hi.y;
     };
-    auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
-    auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
-    auto neg = [](float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); };
-    auto lin = [](float p, float4 a, float q, float4 b) {       // p a + q b
-        return make_float4(fmaf(q, b.x, p * a.x), fmaf(q, b.y, p * a.y), fmaf(q, b.z, p * a.z), fmaf(q, b.w, p * a.w));
-    };
-    // B^T rows: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 = p * (own row) + q * (row of lane 2, 2, 1, 1)
-    const float xp = fr == 3 ? -1.f : 1.f, xq = (fr == 1 || fr == 3) ? 1.f : -1.f;
-    // A rows on the dY tile: xi 0: y0, 1: y0 + y1, 2: y0 - y1, 3: -y1 = p * y0 + q * y1
-    const float yp = fr == 3 ? 0.f : 1.f, yq = fr == 0 ? 0.f : fr == 1 ? 1.f : -1.f;
+    // Row transforms as ONE multiply-add per value, own + q * (a quad neighbour's value):
+    //   B^T rows: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3.  Lane 3 (own row d3) forms d3 - d1, the
+    //   NEGATIVE of row 3 -- and so does the dY side below, so the products of position row 3 are unchanged.
+    //   A rows on the dY tile: xi 0: y0, 1: y0 + y1, 2: y0 - y1, 3: -y1 (stored as +y1, see above).
+    const float xq = fr == 1 ? 1.f : -1.f;                      // neighbour: the row of quad lane 2, 2, 1, 1
+    const float yq = fr == 1 ? 1.f : fr == 2 ? -1.f : 0.f;      // first: y0 (lane 3: y1), second: y1
 
     auto transform = [&](int buf, const Raw &raw) {
         {
-            float4 R[4];
+            P4 R[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) R[b] = lin(xp, raw.x[b], xq, quad_perm<2, 2, 1, 1>(raw.x[b]));
+            for (int b = 0; b < 4; ++b) R[b] = fma2(xq, pk(quad_perm<2, 2, 1, 1>(raw.x[b])), pk(raw.x[b]));
             float *dst = Vs + buf * kOpF;
             put(dst, 0, sub(R[0], R[2]));
             put(dst, 1, add(R[1], R[2]));
@@ -167,14 +173,13 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
         }
         {
             // the quad holds dY[0][0], [0][1], [1][0], [1][1] in lanes 0..3
-            const float4 d00 = quad_perm<0, 0, 0, 0>(raw.y), d01 = quad_perm<1, 1, 1, 1>(raw.y);
-            const float4 d10 = quad_perm<2, 2, 2, 2>(raw.y), d11 = quad_perm<3, 3, 3, 3>(raw.y);
-            const float4 S0 = lin(yp, d00, yq, d10), S1 = lin(yp, d01, yq, d11);
+            const P4 S0 = fma2(yq, pk(quad_perm<2, 2, 2, 2>(raw.y)), pk(quad_perm<0, 0, 0, 2>(raw.y)));
+            const P4 S1 = fma2(yq, pk(quad_perm<3, 3, 3, 3>(raw.y)), pk(quad_perm<1, 1, 1, 3>(raw.y)));
             float *dst = Us + buf * kOpF;
             put(dst, 0, S0);
             put(dst, 1, add(S0, S1));
             put(dst, 2, sub(S0, S1));
-            put(dst, 3, neg(S1));
+            put(dst, 3, P4{-S1.lo, -S1.hi});
         }
     };
 
