@@ -106,6 +106,20 @@ def test_reducer_single_process_views_and_unused():
     assert torch.count_nonzero(model.unused.weight.grad) == 0
     assert torch.count_nonzero(model.sometimes.weight.grad) == 0
     assert torch.count_nonzero(model.shared.weight.grad) > 0
+    # every gradient view starts on a 256-byte boundary of its bucket (the multi-tensor optimizer /
+    # norm kernels vectorise only for aligned pointers), also behind the odd-sized [4] biases
+    for b in red.buckets:
+        for v in b.views:
+            assert (v.data_ptr() - b.flat.data_ptr()) % 256 == 0
+            assert b.flat.data_ptr() <= v.data_ptr() and v.data_ptr() + v.numel() * 4 <= b.flat.data_ptr() + b.numel * 4
+    ref = Toy()
+    ref.load_state_dict(model.state_dict())
+    torch.manual_seed(0)
+    Toy()                                                          # same generator position as above
+    ref(torch.randn(3, 8), use_sometimes=False).backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:
+            assert torch.equal(p.grad, q.grad), n
     opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
     before = model.a.weight.detach().clone()
     torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
