@@ -253,6 +253,83 @@ class _AddLayerNorm(Function):
         return dxv, dres, dgamma, dbeta, None
 
 
+class _FFNAddNorm(Function):
+    """norm(x + linear2(relu(linear1(x)))): the whole FFN sub-block of a post-norm layer
+    (/root/reference/models/dino/deformable_transformer.py:803-806, :879-883) as ONE autograd node --
+    the kernels of _FFNRelu and _AddLayerNorm, in the same order.  What the single node buys is the
+    backward's fan-in: the gradient of the residual path and the FFN's input gradient meet in the
+    beta term of the last GEMM, dx = dsum + dz W1 (`addmm`), instead of a separate add over the
+    token tensor (3 x 91 MB per encoder layer)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        rows = x2.shape[0]
+        h = torch._addmm_activation(b1, x2, w1.t(), use_gelu=False)
+        y = torch.addmm(b2, h, w2.t())
+        out = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _native.lib.datr_add_layernorm_forward_f32(
+                y.data_ptr(), x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, float(eps),
+                out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _native.current_stream_ptr(x.device))
+        _native.check(rc, "add_layernorm_forward")
+        ctx.save_for_backward(x2, h, w1, w2, y, mean, rstd, gamma)
+        ctx.shape = shape
+        return out.view(shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x2, h, w1, w2, y, mean, rstd, gamma = ctx.saved_tensors
+        rows, C = x2.shape
+        d2 = dout.reshape(-1, C)
+        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        dsum = torch.empty_like(x2)                       # gradient of (x + ffn(x)): both addends get it
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        partial = torch.empty(int(_native.lib.datr_add_layernorm_partial_floats(rows)),
+                              device=x2.device, dtype=torch.float32)
+        stream = _native.current_stream_ptr(x2.device)
+        with torch.cuda.device(x2.device):
+            rc = _native.lib.datr_add_layernorm_backward_f32(
+                d2.data_ptr(), y.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                rows, C, dsum.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream)
+        _native.check(rc, "add_layernorm_backward")
+        need = ctx.needs_input_grad
+        dw2 = dsum.t().mm(h) if need[3] else None
+        db2 = column_sums(dsum) if need[4] else None
+        dh = dsum.mm(w2)                                  # rows x d_ffn, ours to overwrite
+        cols = dh.shape[1]
+        db1 = torch.empty(cols, device=dh.device, dtype=dh.dtype)
+        nblk = int(_native.lib.datr_relu_bwd_bias_partial_rows(rows))
+        part2 = torch.empty(nblk * cols, device=dh.device, dtype=dh.dtype)
+        with torch.cuda.device(dh.device):
+            rc = _native.lib.datr_relu_bwd_bias_f32(dh.data_ptr(), h.data_ptr(), rows, cols, part2.data_ptr(),
+                                                    db1.data_ptr(), stream)
+        _native.check(rc, "relu_bwd_bias")
+        dw1 = dh.t().mm(x2) if need[1] else None
+        dx = torch.addmm(dsum, dh, w1).view(ctx.shape) if need[0] else None
+        return (dx, dw1, db1 if need[2] else None, dw2, db2, dgamma if need[5] else None,
+                dbeta if need[6] else None, None)
+
+
+def ffn_add_norm(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear, norm: torch.nn.LayerNorm):
+    """norm(x + linear2(relu(linear1(x)))) as one node, or None when the fused kernels do not apply
+    (the caller then composes ffn_relu / add_layer_norm or the reference's ops)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and linear1.bias is not None
+            and linear2.bias is not None and linear1.out_features % 4 == 0 and linear2.out_features == 256
+            and norm.elementwise_affine and norm.bias is not None and tuple(norm.normalized_shape) == (256,)
+            and torch.is_grad_enabled()):
+        return None
+    return _FFNAddNorm.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight,
+                             norm.bias, norm.eps)
+
+
 def add_layer_norm(x: torch.Tensor, res: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
     """norm(x + res) -- the tail of every post-norm sub-block
     (/root/reference/models/dino/deformable_transformer.py:796-806, :856-893).  Device float32

@@ -110,6 +110,21 @@ def _ffn(x, linear1, activation, dropout, linear2):
     return linear2(dropout(activation(linear1(x))))
 
 
+FUSED_FFN_BLOCK = __import__("os").environ.get("DATR_FUSED_FFN_BLOCK", "1") != "0"   # A/B switch
+
+
+def _ffn_block(x, linear1, activation, dropout_a, linear2, dropout_b, norm):
+    """norm(x + dropout_b(linear2(dropout_a(activation(linear1(x)))))): the FFN sub-block; one autograd
+    node on the device (fused.ffn_add_norm) when both fused halves apply, else their composition."""
+    if (FUSED_FFN_BLOCK and FUSED_FFN and FUSED_ADD_NORM and activation is F.relu and x.is_cuda
+            and not (dropout_a.training and dropout_a.p > 0) and not (dropout_b.training and dropout_b.p > 0)):
+        from .fused import ffn_add_norm
+        out = ffn_add_norm(x, linear1, linear2, norm)
+        if out is not None:
+            return out
+    return _add_norm(x, _ffn(x, linear1, activation, dropout_a, linear2), dropout_b, norm)
+
+
 def _activation(name: str):
     table = {"relu": F.relu, "gelu": F.gelu, "glu": F.glu, "selu": F.selu}
     if name not in table:
@@ -228,8 +243,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         src = _add_norm(src, self.self_attn(q, reference_points, src, spatial_shapes,
                                             level_start_index, key_padding_mask),
                         self.dropout1, self.norm1)
-        ffn = _ffn(src, self.linear1, self.activation, self.dropout2, self.linear2)
-        return _add_norm(src, ffn, self.dropout3, self.norm2)
+        return _ffn_block(src, self.linear1, self.activation, self.dropout2, self.linear2, self.dropout3, self.norm2)
 
 
 class TransformerEncoder(nn.Module):
@@ -305,8 +319,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.key_aware_proj = None
 
     def forward_ffn(self, tgt):
-        tgt2 = _ffn(tgt, self.linear1, self.activation, self.dropout3, self.linear2)
-        return _add_norm(tgt, tgt2, self.dropout4, self.norm3)
+        return _ffn_block(tgt, self.linear1, self.activation, self.dropout3, self.linear2, self.dropout4, self.norm3)
 
     def forward_sa(self, tgt, query_pos, attn_mask):
         q = k = tgt if query_pos is None else tgt + query_pos

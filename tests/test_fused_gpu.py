@@ -472,3 +472,41 @@ def test_level_embedding_add_matches_the_per_level_formula():
     assert torch.equal(b, torch.cat([p.flatten(2).transpose(1, 2) + tr.level_embed[l].view(1, 1, -1)
                                      for l, p in enumerate(pos2)], 1))
     assert torch.equal(tr._level_positions(pos), a)
+
+
+@pytest.mark.parametrize("rows", [(3, 700), (2, 4400)])
+def test_ffn_block_as_one_node_matches_composition_and_float64(rows):
+    """fused._FFNAddNorm (FFN + residual + LayerNorm as one autograd node, the residual gradient
+    riding in the last GEMM's beta term) against the composition of the two fused halves and against
+    the reference's op sequence in float64 (deformable_transformer.py:803-806)."""
+    import torch.nn.functional as F
+    from datr_amd import transformer as T
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows[1])
+    lin1, lin2, norm = torch.nn.Linear(256, 2048).to(dev), torch.nn.Linear(2048, 256).to(dev), torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.normal_(0, 0.1)
+    drop = torch.nn.Dropout(0.0)
+    x = torch.randn(*rows, 256, device=dev, requires_grad=True)
+    go = torch.randn(*rows, 256, device=dev)
+    params = [lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm.weight, norm.bias]
+    outs = {}
+    for one in (True, False):
+        T.FUSED_FFN_BLOCK = one
+        y = T._ffn_block(x, lin1, F.relu, drop, lin2, drop, norm)
+        outs[one] = (y, torch.autograd.grad(y, [x] + params, go))
+    T.FUSED_FFN_BLOCK = True
+    assert "FFNAddNorm" in type(outs[True][0].grad_fn).__name__
+    assert torch.equal(outs[True][0], outs[False][0])                      # same kernels forward
+    xd = x.detach().double().requires_grad_(True)
+    pd = [p.detach().double().requires_grad_(True) for p in params]
+    yd = F.layer_norm(xd + F.linear(F.relu(F.linear(xd, pd[0], pd[1])), pd[2], pd[3]), (256,), pd[4], pd[5])
+    gd = torch.autograd.grad(yd, [xd] + pd, go.double())
+    for a, b, r in zip(outs[True][1], outs[False][1], gd):
+        scale = float(r.abs().max())
+        # against float64 a handful of ReLU gates sit within float32 rounding of zero and flip (each taking the 256 values of its row along): isolated
+        # outliers, not a tolerance; against the composed float32 path (same h) there are none
+        off = (a.double() - r).abs() > 2e-5 * scale + 1e-6
+        assert float(off.double().mean()) <= 2e-3 and float((a.double() - r).abs().max()) <= 0.05 * scale
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6
