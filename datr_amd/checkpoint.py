@@ -44,6 +44,12 @@ def load_model_state(model: torch.nn.Module, checkpoint, key: Optional[str] = No
 def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, args=None,
                     ema_model=None):
     """checkpoint.pth layout of main.py:401-412 (model saved without a DDP wrapper)."""
+    if getattr(args, "reducer", None) is not None:
+        # run-time objects are not configuration: a caller-supplied gradient reducer (flat buckets,
+        # hook handles, streams) must not be pickled with the args bag
+        import copy
+        args = copy.copy(args)
+        args.reducer = None
     weights = {"model": model.state_dict(), "epoch": epoch, "args": args}
     if optimizer is not None:
         weights["optimizer"] = optimizer.state_dict()

@@ -92,6 +92,12 @@ extern "C" int datr_nms_f32(const float *boxes, const float *scores, const int64
     if (n > kMaxBoxes) return DATR_EUNSUPPORTED;
     if (n > 0 && (!boxes || !scores || !labels || !keep)) return DATR_EINVAL;
     const size_t lds = (size_t)n * (4 + 1 + 1 + 1) * sizeof(float);
+    // above 64 KiB of dynamic LDS (n > 2340) a launch needs the opt-in; kMaxBoxes * 28 B = 112 KiB
+    // fits the 160 KiB of a gfx950 CU
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    kMaxBoxes * 7 * (int)sizeof(float)) == hipSuccess;
+    if (!attr_ok && lds > 64 * 1024) return DATR_EUNSUPPORTED;
     hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(kThreads), lds, (hipStream_t)stream, boxes, scores, labels,
                        (int)n, iou_threshold, keep, count);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;

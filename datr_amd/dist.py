@@ -34,6 +34,7 @@ identity, as `nn.Module.parameters()` already does.
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional
 
 import torch
@@ -312,20 +313,36 @@ class GradAllReducer:
         return sum(b.numel for b in self.buckets) * 4
 
 
+# model -> its reducer (False = "none, and do not create one").  A weak registry rather than an
+# attribute of the model or of the args bag: the reference pickles `args` into every checkpoint
+# (/root/reference/main.py:401-412) and deep-copies the model for the EMA teacher (EMA.py:33) --
+# neither may drag 191 MB of flat gradient buckets, hook handles and stream objects along.
+_REDUCERS = weakref.WeakKeyDictionary()
+
+
+def attach_reducer(model: nn.Module, reducer) -> None:
+    """Registers `reducer` (a GradAllReducer, or False to forbid the on-demand one) for `model`."""
+    _REDUCERS[model] = reducer
+
+
 def reducer_for(model: nn.Module, args=None) -> Optional[GradAllReducer]:
-    """The reducer the epoch functions (datr_amd.engine) synchronise gradients with: `args.reducer`
-    if the caller made one, otherwise one per model, created on first use whenever a process
-    group with more than one rank is up (or DATR_DIST_FORCE_COLLECTIVES=1) and the model is not
-    already wrapped in DistributedDataParallel.  None = single process, plain `.grad`s."""
+    """The reducer the epoch functions (datr_amd.engine) synchronise gradients with: the one
+    registered for the model (`attach_reducer`, `training.build_training`), otherwise one per model
+    created on first use whenever a process group with more than one rank is up (or
+    DATR_DIST_FORCE_COLLECTIVES=1) and the model is not already wrapped in
+    DistributedDataParallel.  None = single process, plain `.grad`s.  (`args.reducer`, if a caller
+    put one there, still wins -- but nothing in this package stores it on the args bag.)"""
     r = getattr(args, "reducer", None) if args is not None else None
     if r is not None:
         return r
     if isinstance(model, nn.parallel.DistributedDataParallel):
         return None
-    r = model.__dict__.get("_grad_reducer")
+    r = _REDUCERS.get(model)
+    if r is False:
+        return None
     if r is None and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
         r = GradAllReducer(model)
-        model.__dict__["_grad_reducer"] = r
+        _REDUCERS[model] = r
     return r
 
 

@@ -94,6 +94,11 @@ def _ema_update_(ema_model: nn.Module, model: nn.Module, d: float) -> None:
         if plan is None or plan.key != key:
             plan = _PLANS[id(ema_model)] = _DevicePlan(dev, dev[0][0].device)
         plan.run(d)
+        # The kernel writes through raw pointers: autograd's version counters must move as they
+        # would under `v *= d`, or caches keyed on (data_ptr, _version) -- the folded frozen-BN
+        # weights of pointwise.fold_frozen_bn, FrozenBatchNorm2d.scale_shift -- keep serving the
+        # teacher's weights from before the update.
+        torch._C._increment_version([v for v, _, _ in dev])
     for k, (dst, src) in host.items():
         for _ in range(k):
             torch._foreach_mul_(dst, d)

@@ -9,11 +9,19 @@ from torch.autograd.function import once_differentiable
 
 from . import _native
 
+# The kernels behind these nodes read raw float32 pointers.  Under torch.autocast (engine.py runs the
+# model under it when args.amp is set, /root/reference/engine.py:59) a torch.mm / addmm INSIDE a
+# forward would come back in half precision; custom_fwd runs the node with autocast off (its float
+# inputs arrive as float32), custom_bwd gives the backward the same state.
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 class _AffineAct(Function):
     """y = act(x * scale[c] + shift[c] (+ res)) over NCHW tensors; one HBM pass each way."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, scale, shift, res, relu):
         N, C, H, W = x.shape
         # NHWC (channels_last) tensors are processed in place of layout: channel = i % C
@@ -37,6 +45,7 @@ class _AffineAct(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         y, scale = ctx.saved_tensors
         C, inner, fmt = ctx.shape
@@ -71,6 +80,7 @@ class _GroupNormNHWC(Function):
     (csrc/groupnorm.hip)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, gamma, beta, groups, eps):
         N, C, H, W = x.shape
         y = torch.empty_like(x, memory_format=torch.channels_last)
@@ -89,6 +99,7 @@ class _GroupNormNHWC(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         N, C, H, W = x.shape
@@ -156,6 +167,7 @@ class _FFNRelu(Function):
     Same saved activations as autograd's own graph (x and h)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w1, b1, w2, b2):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
@@ -167,6 +179,7 @@ class _FFNRelu(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         x2, h, w1, w2 = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -206,6 +219,7 @@ class _AddLayerNorm(Function):
     (the sum) -- and recomputes x + res in backward."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, res, gamma, beta, eps):
         shape = x.shape
         C = shape[-1]
@@ -232,6 +246,7 @@ class _AddLayerNorm(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         x2, r2, mean, rstd, gamma = ctx.saved_tensors
         rows, C = x2.shape
@@ -262,6 +277,7 @@ class _FFNAddNorm(Function):
     token tensor (3 x 91 MB per encoder layer)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
         shape = x.shape
         C = shape[-1]
@@ -284,6 +300,7 @@ class _FFNAddNorm(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dout):
         x2, h, w1, w2, y, mean, rstd, gamma = ctx.saved_tensors
         rows, C = x2.shape
@@ -428,6 +445,7 @@ class _LinearFn(Function):
     (19 us for a [4400, 256] gradient, 41 us for [88892, 256]; ~90 of them per step)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, b):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
@@ -441,6 +459,7 @@ class _LinearFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -501,6 +520,7 @@ def conv3x3_lrelu_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
 # ---------------------------------------------------------------------------------------------
 class _AttentionD32(Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, q, k, v, mask, heads):
         L, N, E = q.shape
         out = torch.empty(L, N, E, device=q.device, dtype=torch.float32)
@@ -519,6 +539,7 @@ class _AttentionD32(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dout):
         q, k, v, out, lse, mask = ctx.saved_tensors
         L, N, E = q.shape

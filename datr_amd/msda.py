@@ -275,11 +275,14 @@ class OffsetMonitor:
                                  s = 6               373 / 7107        249 / 5191             3645
                                  uniform             530 / 51238       272 / 11461            4668
     Every `every`-th call the fraction f of (sub-sampled) samples whose offset exceeds the halo in
-    x or y is computed on the device and copied to pinned memory without synchronising; a later
-    call that finds the copy complete updates the route: f < 0.25 -> 0 (pyramid), f < 0.62 -> 1 (row
-    forward, query-tiled backward), else 2 (row kernels).  One step of lag, no host sync."""
+    x or y is computed on the device and copied to pinned memory without synchronising; the call
+    `LAG` calls later -- a fixed count, so the step at which a route flips does not depend on host /
+    GPU timing and runs are reproducible; by then the copy completed long ago and the event wait
+    returns at once -- updates the route: f < 0.25 -> 0 (pyramid), f < 0.62 -> 1 (row forward,
+    query-tiled backward), else 2 (row kernels).  `DATR_MSDA_ADAPTIVE=0` pins route 0."""
 
     HALO_PX = 4.5
+    LAG = 8                 # calls between a measurement and its use (>= one training step's worth)
 
     def __init__(self, every: int = 50):
         self.every, self.calls, self.route, self.fraction = every, 0, 0, 0.0
@@ -290,7 +293,8 @@ class OffsetMonitor:
         return 0 if fraction < 0.25 else (1 if fraction < 0.62 else 2)
 
     def poll(self):
-        if self._pending is not None and self._pending[1].query():
+        if self._pending is not None and self.calls >= self._pending[2] + self.LAG:
+            self._pending[1].synchronize()
             self.fraction = float(self._pending[0][0])
             self.route = self.route_for(self.fraction)
             self._pending = None
@@ -310,7 +314,7 @@ class OffsetMonitor:
             host.copy_(far.float().mean().view(1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        self._pending = (host, ev)
+        self._pending = (host, ev, self.calls)
 
 
 _MONITORS = weakref.WeakKeyDictionary()            # module -> OffsetMonitor (not part of the module:

@@ -19,7 +19,7 @@ import torch
 
 from . import detector  # noqa: F401  (registers 'dino' in MODULE_BUILD_FUNCS)
 from .config import c2f_args, get_param_dict
-from .dist import FORCE_COLLECTIVES, GradAllReducer
+from .dist import FORCE_COLLECTIVES, GradAllReducer, attach_reducer
 from .nested import NestedTensor
 from .registry import MODULE_BUILD_FUNCS
 
@@ -30,7 +30,8 @@ def build_training(cfg: Optional[argparse.Namespace] = None, device="cuda", *, s
     """Returns a Namespace(model, criterion, postprocessors, optimizer, reducer, cfg).
     `reducer`: True / False force the flat-bucket gradient reducer on / off; None = on whenever a
     process group with more than one rank is up (or DATR_DIST_FORCE_COLLECTIVES=1).  The reducer
-    is also stored as `cfg.reducer`, where the epoch functions look for it."""
+    is registered for the model (`dist.attach_reducer`), where the epoch functions look it up --
+    NOT stored on `cfg`, which the checkpoint format pickles (`'args': args`, main.py:401-412)."""
     import torch.distributed as dist
     device = torch.device(device)
     if cfg is None:
@@ -51,31 +52,35 @@ def build_training(cfg: Optional[argparse.Namespace] = None, device="cuda", *, s
     if reducer is None:
         reducer = dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
     red = GradAllReducer(model) if reducer else None
-    cfg.reducer = red
+    attach_reducer(model, red if red is not None else False)
     return argparse.Namespace(model=model, criterion=criterion, postprocessors=postprocessors,
                               optimizer=optimizer, reducer=red, cfg=cfg, device=device)
 
 
 def synthetic_batch(batch_size, height, width, num_gt, device, seed, channels_last=True,
-                    pad_to=None):
+                    pad_to=None, source_only=False):
     """images randn [2B,3,H,W] (already 'normalised'); per source image `num_gt`
     boxes, labels in 1..8, cxcy ~ U(0.2,0.8), wh ~ U(0.05,0.25).  Returned in the epoch
     functions' batch format `(samples, targets, _, _)` pieces: (NestedTensor, tuple of dicts).
     `pad_to=(H', W')`: the images sit in the top-left corner of a larger zero-padded batch
     tensor with the collate function's mask (True on padding), as a batch of different-sized
-    images would -- the padded (general) path of the model instead of the no-padding fast one."""
+    images would -- the padded (general) path of the model instead of the no-padding fast one.
+    `source_only`: B source images and no target images (BASELINE configs 1-2: the model's
+    `domain_adaptation = False` step); the source images and targets are the same as in the pair."""
     g = torch.Generator().manual_seed(seed)
     imgs = torch.randn(2 * batch_size, 3, height, width, generator=g)
+    if source_only:
+        imgs = imgs[:batch_size].clone()
     H, W = (height, width) if pad_to is None else pad_to
     padded = (H, W) != (height, width)
     if padded:
-        full = torch.zeros(2 * batch_size, 3, H, W)
+        full = torch.zeros(imgs.shape[0], 3, H, W)
         full[:, :, :height, :width] = imgs
-        mask = torch.ones(2 * batch_size, H, W, dtype=torch.bool)
+        mask = torch.ones(imgs.shape[0], H, W, dtype=torch.bool)
         mask[:, :height, :width] = False
         imgs = full
     else:
-        mask = torch.zeros(2 * batch_size, H, W, dtype=torch.bool)
+        mask = torch.zeros(imgs.shape[0], H, W, dtype=torch.bool)
     targets = []
     for _ in range(batch_size):
         cxcy = torch.rand(num_gt, 2, generator=g) * 0.6 + 0.2

@@ -189,3 +189,65 @@ def check_gradients(model, g, rtol=2e-2, outlier_fraction=0.0):
                     (key, float(miss.float().mean()), float(err.max()), scale)
                 continue
             torch.testing.assert_close(mine, want, rtol=2e-2, atol=2e-3 * scale)
+
+
+DA_LOSS_KEYS = ("loss_backbone_DA", "loss_proto_DA", "loss_global_proto_DA")
+
+
+def run_source_only_step(model, criterion, device, golden, channels_last=False):
+    """BASELINE configs 1-2 (SURVEY.md 8d "Mapping BASELINE configs"): the non-reference switch
+    `model.domain_adaptation = False` -- no D_img / prototypes / target pass, B source images only.
+    The source-side outputs and every non-DA loss of the reference's step do not depend on the DA
+    branch in the forward pass, so the golden step pins them.  The source image of the synthetic
+    pair is the larger one: alone in a batch it is unpadded exactly as inside the pair."""
+    import synth
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    imgs, targets = synth.synth_batch()
+    samples = nested_tensor_from_tensor_list([imgs[0].to(device)])
+    if channels_last:
+        samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
+    targets = [{k: v.to(device) for k, v in tg.items()} for tg in targets]
+    model.domain_adaptation = False
+    model.train()
+    criterion.train()
+    model.dn_noise_override = {
+        "label_p": t(golden["noise_label_p"]), "new_label": t(golden["noise_new_label"]),
+        "rand_sign": t(golden["noise_rand_sign"]), "rand_part": t(golden["noise_rand_part"])}
+    src_idx = t(golden["topk_source"]).to(device)
+    model.transformer.select_queries = lambda scores: src_idx
+    out = model(samples, targets)
+    loss_dict, indices_list = criterion(out, targets, return_indices=True)
+    wd = criterion.weight_dict
+    total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+    model.zero_grad()
+    total.backward()
+    return out, loss_dict, indices_list, total
+
+
+def check_source_side(out, loss_dict, indices_list, g, logit_tol=1e-3, loss_rtol=2e-3):
+    """Source-side outputs, Hungarian indices and all non-DA losses against model_step.npz."""
+    cpu = lambda x: x.detach().float().cpu()
+    close = lambda a, b, **kw: torch.testing.assert_close(cpu(a), t(b), **kw)
+    kw = dict(rtol=logit_tol, atol=logit_tol)
+    assert "da_output" not in out
+    close(out["pred_logits"], g["pred_logits"], **kw)
+    close(out["pred_boxes"], g["pred_boxes"], **kw)
+    close(torch.stack([a["pred_logits"] for a in out["aux_outputs"]]), g["aux_logits"], **kw)
+    close(torch.stack([a["pred_boxes"] for a in out["aux_outputs"]]), g["aux_boxes"], **kw)
+    close(out["interm_outputs"]["pred_logits"], g["interm_logits"], **kw)
+    close(out["interm_outputs"]["pred_boxes"], g["interm_boxes"], **kw)
+    close(out["interm_outputs_for_matching_pre"]["pred_boxes"], g["init_box_proposal"], **kw)
+    known = out["dn_meta"]["output_known_lbs_bboxes"]
+    assert out["dn_meta"]["pad_size"] == int(g["dn_pad_size"])
+    close(known["pred_logits"], g["dn_logits"], **kw)
+    close(known["pred_boxes"], g["dn_boxes"], **kw)
+    mine = np.stack([np.stack([np.stack([s.cpu().numpy(), tt.cpu().numpy()]) for s, tt in call])
+                     for call in indices_list])
+    assert mine.shape == g["indices"].shape and (mine == g["indices"]).all()
+    ref_keys = [str(k) for k in g["loss_keys"]]
+    want_keys = [k for k in ref_keys if k not in DA_LOSS_KEYS]
+    assert list(loss_dict.keys()) == want_keys and len(want_keys) == 79
+    ref = dict(zip(ref_keys, g["loss_values"].tolist()))
+    mine_vals = torch.tensor([float(loss_dict[k].detach()) for k in want_keys], dtype=torch.float64)
+    want_vals = torch.tensor([ref[k] for k in want_keys], dtype=torch.float64)
+    torch.testing.assert_close(mine_vals, want_vals, rtol=loss_rtol, atol=loss_rtol * 0.1)

@@ -267,8 +267,9 @@ def _dino_worker(rank, world, port, tmp):
             w = model.transformer.level_embed.detach().clone()
             dist.broadcast(w, 0)
             assert torch.equal(w, model.transformer.level_embed)
-            ref = copy.deepcopy(model)
-            ref.__dict__.pop("_grad_reducer", None)
+            ref = copy.deepcopy(model)       # the reducer lives in a weak registry, not on the model
+            from datr_amd.dist import attach_reducer
+            attach_reducer(ref, False)
         else:
             ref.load_state_dict(model.state_dict())
             ref.global_proto, ref.Amount = proto_before

@@ -164,6 +164,22 @@ def test_source_only_switch(monkeypatch):
     assert "loss_backbone_DA" not in losses and "loss_ce_dn_4" in losses
 
 
+def test_source_only_step_matches_reference_source_side(monkeypatch):
+    """BASELINE config 1-2 semantics pinned against the reference: with the DA branch off, the
+    source-side outputs, the 7 Hungarian assignments and all 79 non-DA losses equal those of the
+    reference's full step (/root/reference/models/dino/dino.py:278-279,351-415 show
+    the DA branch only ADDS outputs in the forward pass)."""
+    from helpers import check_source_side, run_source_only_step
+    patch_msda_with_oracle(monkeypatch, kind="grid_sample")
+    g = load_npz("model_step.npz")
+    _, model, criterion, _ = build_model()
+    out, loss_dict, indices_list, _ = run_source_only_step(model, criterion, torch.device("cpu"), g)
+    check_source_side(out, loss_dict, indices_list, g, logit_tol=1e-4, loss_rtol=1e-4)
+    # no DA parameter is touched
+    assert all(p.grad is None for n, p in model.named_parameters()
+               if n.startswith(("D_img.", "Proto_D.")))
+
+
 def test_no_padding_fast_path_is_identical(monkeypatch):
     """Equal-size images: `nested_tensor_from_tensor_list` records padded=False on the host and
     the model skips the all-False `masked_fill` and re-uses cached position embeddings

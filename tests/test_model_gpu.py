@@ -103,6 +103,22 @@ def test_nhwc_step_with_reference_selection_matches_elementwise(monkeypatch):
     check_gradients(model, g, rtol=3e-2, outlier_fraction=0.05)
 
 
+def test_source_only_step_on_device_matches_reference_source_side():
+    """BASELINE config 2 (burn-in with the DA branch off) on the HIP path, NCHW and bench.py's NHWC
+    layout: source-side outputs within 1e-3, Hungarian indices bit-exact, the 79 non-DA losses."""
+    from helpers import check_source_side, run_source_only_step
+    dev = torch.device("cuda:0")
+    g = load_npz("model_step.npz")
+    for nhwc in (False, True):
+        _, model, criterion, _ = build_model("cuda:0")
+        if nhwc:
+            model.backbone.to(memory_format=torch.channels_last)
+        out, loss_dict, indices_list, _ = run_source_only_step(model, criterion, dev, g, channels_last=nhwc)
+        check_source_side(out, loss_dict, indices_list, g, logit_tol=1e-3, loss_rtol=2e-3)
+        assert all(p.grad is None for n, p in model.named_parameters()
+                   if n.startswith(("D_img.", "Proto_D.")))
+
+
 def test_every_trainable_parameter_gets_a_finite_gradient(step):
     g, model, *_ = step
     norms = canonical_grad_norms(model)
