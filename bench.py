@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
+PMC_RECORD = "r03_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
 
 
 from datr_amd.training import build_training, run_steps, synthetic_batch  # noqa: E402
@@ -58,17 +59,17 @@ class MsdaTimer:
         self.enabled = False
 
     def install(self):
-        def timed(value, shapes, lsi, loc, attn, step):
+        def timed(value, shapes, lsi, loc, attn, step, **kw):
             if self.enabled and loc.shape[1] == value.shape[1]:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                out = self.orig(value, shapes, lsi, loc, attn, step)
+                out = self.orig(value, shapes, lsi, loc, attn, step, **kw)
                 b.record()
                 self.events.append((a, b))
                 self.shape = (value.shape[0], value.shape[1], value.shape[2], value.shape[3],
                               loc.shape[3] * loc.shape[4], loc.shape[1])
                 return out
-            return self.orig(value, shapes, lsi, loc, attn, step)
+            return self.orig(value, shapes, lsi, loc, attn, step, **kw)
         self.msda.ms_deform_attn_forward = timed
 
     def result(self):
@@ -82,13 +83,20 @@ class MsdaTimer:
         # N = 4 launch; FETCH_SIZE corrected as the micro-architecture guide prescribes).  PMC
         # counters cannot be collected inside this process: null when the shape differs.
         traffic, kernel = None, "msda forward (encoder call)"
-        pmc = os.path.join(ROOT, "profiles", "r02_msda_pmc.json")
+        traffic_src = None
+        pmc = os.path.join(ROOT, "profiles", PMC_RECORD)
         if os.path.exists(pmc):
+            # raw per-launch counter rows of the committed rocprofv3 PMC passes; the formula is
+            # applied HERE so that the number reproduces from the committed rows:
+            # bytes = (2 x mean FETCH_SIZE [KB] + mean WRITE_SIZE [KB]) x 1024
             rec = json.load(open(pmc))
             sh = rec["shape"]
             if (sh["N"], sh["S"], sh["M"], sh["D"], sh["Lq"]) == (N, S, M, D, Lq) and sh["L"] * sh["P"] == K \
                     and self.msda.PYR_FORWARD:
-                traffic = int(rec["traffic_bytes"])
+                fetch, write = rec["FETCH_SIZE_KB_per_launch"], rec["WRITE_SIZE_KB_per_launch"]
+                traffic = int(round((2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024))
+                traffic_src = f"profiles/{PMC_RECORD}: (2 x mean FETCH_SIZE + mean WRITE_SIZE) x 1024, " \
+                              f"{len(fetch)} + {len(write)} launches"
         if self.msda.PYR_FORWARD and D == 32 and K == 16:
             kernel = "msda_fwd_pyr_d32 (encoder call, csrc/msda_fwd_pyr.hip)"
         else:
@@ -96,7 +104,7 @@ class MsdaTimer:
         achieved = algo_bytes / mean_us / 1e3
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "kernel": kernel, "launches": len(us),
+                "traffic_source": traffic_src, "kernel": kernel, "launches": len(us),
                 "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
 
 
@@ -266,6 +274,14 @@ def cpu_baseline(msda_gpu_us=None):
         t0 = time.perf_counter()
         step()
         dt = time.perf_counter() - t0
+        # BASELINE config 1 as stated: ONE image 640x640, source-only (DA branch off)
+        model.domain_adaptation = False
+        samples, targets = synthetic_batch(1, 640, 640, 5, torch.device("cpu"), seed=1, source_only=True)
+        targets = list(targets)
+        step()
+        t0 = time.perf_counter()
+        step()
+        dt1 = time.perf_counter() - t0
     finally:
         msda.ms_deform_attn_forward, msda.ms_deform_attn_backward, crit_mod.focal_loss_sums = saved
     return {"value": round(2.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
@@ -273,6 +289,10 @@ def cpu_baseline(msda_gpu_us=None):
             "sample": f"1 training step (after 1 warm-up step), 1 source + 1 target image 640x640 "
                       f"(BASELINE config 1 shape, DA branch included), {dt:.1f} s on "
                       f"{os.cpu_count()} host cpus",
+            "config1_source_only": {"value": round(1.0 / dt1, 4), "unit": "images/s",
+                                    "sample": f"1 training step (after 1 warm-up step), 1 source image "
+                                              f"640x640, DA branch off (BASELINE config 1 as stated), "
+                                              f"{dt1:.1f} s"},
             "msda_op": msda_cpu_ops(msda_gpu_us)}
 
 
@@ -311,9 +331,12 @@ def main():
                          "MIOpen's measured-fastest fp32 solvers want; same arithmetic)")
     ap.add_argument("--no-tuned-gemm", dest="tuned_gemm", action="store_false",
                     help="leave hipBLASLt on its default heuristic (datr_amd/tuning)")
-    ap.add_argument("--stage", choices=["burn-in", "teacher"], default="burn-in",
+    ap.add_argument("--stage", choices=["burn-in", "source-only", "teacher"], default="burn-in",
                     help="teacher: the teacher-student stage (BASELINE config 5) on one GPU; "
-                         "the default is the headline burn-in step")
+                         "source-only: BASELINE config 2 read literally -- the burn-in step with the "
+                         "DA branch off (model.domain_adaptation = False: B source images, no "
+                         "target pass, no D_img / prototypes); the default is the headline burn-in "
+                         "step, which is the reference's real one (DA branch on, config 3)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_with_ranks(args.gpus)
@@ -335,9 +358,13 @@ def main():
     state = build_training(device=device, rank=rank, channels_last=args.channels_last,
                            tuned_gemm=args.tuned_gemm,
                            reducer=True if (world > 1 or FORCE_COLLECTIVES or args.flat_grads) else False)
+    source_only = args.stage == "source-only"
+    if source_only:
+        state.model.domain_adaptation = False
     # four different batches of the workload's shape, cycled (a data loader's batches differ)
     pool = [synthetic_batch(args.batch, args.height, args.width, args.num_gt, device,
-                            seed=1 + 7 * rank + 1000 * i, channels_last=args.channels_last)
+                            seed=1 + 7 * rank + 1000 * i, channels_last=args.channels_last,
+                            source_only=source_only)
             for i in range(4)]
     timer = MsdaTimer()
     timer.install()
@@ -366,7 +393,7 @@ def main():
     elapsed = float(t.item())
 
     padded_ms = None
-    if args.padded_steps > 0 and world == 1:
+    if args.padded_steps > 0 and world == 1 and not source_only:
         # the same workload as a batch of different-sized images would arrive: images of
         # (H-32) x W inside the H x W batch tensor, mask True on the padding
         pb = synthetic_batch(args.batch, args.height - 32, args.width, args.num_gt, device, seed=99,
@@ -379,29 +406,35 @@ def main():
         padded_ms = round((time.perf_counter() - t1) / args.padded_steps * 1e3, 2)
 
     if rank == 0:
-        images = 2 * args.batch * world * args.steps
+        per_gpu = args.batch if source_only else 2 * args.batch
+        images = per_gpu * world * args.steps
         roof = timer.result()
         line = {
-            "metric": "images/sec, DINO-4scale R50 + DATR DA branch training step, bs=2/GPU, 1333x800",
+            "metric": ("images/sec, DINO-4scale R50 source-only training step (DA branch off), bs=2/GPU, "
+                       "1333x800" if source_only else
+                       "images/sec, DINO-4scale R50 + DATR DA branch training step, bs=2/GPU, 1333x800"),
             "value": round(images / elapsed, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": "DINO-4scale R50 bs=2 1333x800 burn-in step through "
-                                   "engine.train_one_epoch (fwd + SetCriterion + reduce_dict + bwd + "
-                                   "grad all-reduce + clip + AdamW + loss fetch/guard; source+target "
-                                   "pass, D_img, prototypes)",
-                       "images_per_gpu": 2 * args.batch, "global_batch_pairs": args.batch * world,
+            "config": {"workload": ("BASELINE config 2 read literally: DINO-4scale R50 bs=2 1333x800 burn-in "
+                                    "step with the DA branch off (2 source images, no target pass) "
+                                    "through engine.train_one_epoch" if source_only else
+                                    "DINO-4scale R50 bs=2 1333x800 burn-in step through "
+                                    "engine.train_one_epoch (fwd + SetCriterion + reduce_dict + bwd + "
+                                    "grad all-reduce + clip + AdamW + loss fetch/guard; source+target "
+                                    "pass, D_img, prototypes)"),
+                       "images_per_gpu": per_gpu, "global_batch_pairs": args.batch * world,
                        "parallelism": f"dp{world}", "num_gt_per_image": args.num_gt,
                        "grad_reducer": state.reducer is not None,
                        "rccl_world": dist.get_world_size() if dist.is_initialized() else 1},
-            "pairs_per_sec": round(images / elapsed / 2, 3),
+            "pairs_per_sec": round(images / elapsed / (1 if source_only else 2), 3),
             "padded_batch_ms_per_step": padded_ms,
             "roofline": roof,
         }
         if timer.shape is not None:
             line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not source_only:
             if dist.is_initialized():       # one-rank RCCL mode: the CPU leg must not see a NCCL group
                 dist.destroy_process_group()
             # GPU time of the op at the CPU leg's shape (N=2): the merged N=4 launch / 2

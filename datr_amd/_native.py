@@ -29,6 +29,8 @@ _SIGNATURES = {
     "datr_msda_forward_tiled_f32": [_vp] * 7 + [_i64] * 7 + [_vp, _vp],
     "datr_msda_backward_tiled_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
     "datr_msda_backward_query_tiled_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
+    "datr_msda_forward_pyramid_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp],
+    "datr_msda_pyramid_plan": [_vp, _vp] + [_i64] * 7 + [_vp, _vp],
     "datr_msda_uses_fast_path": [_i64] * 5,
     "datr_affine_act_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
     "datr_affine_act_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],

@@ -393,17 +393,11 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
 
 }  // namespace
 
-// Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
-// grad_value must be zero-filled by the caller.
-extern "C" int datr_internal_msda_bwd_pyr_d32(
-    const float *grad_out, const float *value, const float *loc, const float *attn,
-    const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
-    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value, float *grad_loc,
-    float *grad_attn, void *stream)
-{
-    if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || N < 1) return DATR_EUNSUPPORTED;
+// Region plan of the backward kernel; false when the shape is not covered.
+static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t *level_start_host,
+                         int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P) {
+    if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || N < 1) return false;
     static const float halo = pyr_halo_from_env();
-    PyrMeta pm;
     const auto fits = [](const PyrMeta &m_, int most_queries) {
         int rows = 0;
         for (int l = 0; l < 4; ++l) rows = std::max(rows, m_.WH[l] * m_.WW[l]);
@@ -411,7 +405,7 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
     };
     if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, kMaxQ >= 512 ? 12.5 : 10.0,
                         kMaxQ >= 512 ? 28.0 : 16.7, fits))
-        return DATR_EUNSUPPORTED;
+        return false;
     // The windows are index spaces here (nothing is staged), so the halo may be as wide as the
     // 1024-row histogram allows: samples beyond it take the slow direct-atomic path.
     {
@@ -426,6 +420,28 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
             }
         }
     }
+    return true;
+}
+
+// info[0..2] = {covered, nRy, nRx} of the backward plan (no launch)
+extern "C" int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+                                               int64_t S, int64_t M, int32_t *info) {
+    PyrMeta pm;
+    const bool ok = bwd_pyr_plan(pm, shapes_host, level_start_host, 1, S, M, 32, 4, S, 4);
+    info[0] = ok; info[1] = ok ? pm.nRy : 0; info[2] = ok ? pm.nRx : 0;
+    return ok ? DATR_OK : DATR_EUNSUPPORTED;
+}
+
+// Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
+// grad_value must be zero-filled by the caller.
+extern "C" int datr_internal_msda_bwd_pyr_d32(
+    const float *grad_out, const float *value, const float *loc, const float *attn,
+    const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value, float *grad_loc,
+    float *grad_attn, void *stream)
+{
+    PyrMeta pm;
+    if (!bwd_pyr_plan(pm, shapes_host, level_start_host, N, S, M, D, L, Lq, P)) return DATR_EUNSUPPORTED;
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     kLdsBytes) == hipSuccess;

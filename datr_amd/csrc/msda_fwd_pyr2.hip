@@ -1,0 +1,570 @@
+// msda_fwd_pyr2.hip -- MSDA forward for the encoder calls (Lq == S, D == 32, L == P == 4), round 3:
+// ALL FOUR LEVELS gathered out of LDS, in phases, windows sized by a per-head offset envelope.
+//
+// Reference behaviour: /root/reference/models/dino/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299
+// (sampling + aggregation; pixel mapping h = y*H - 0.5, in-range test :285-288).
+//
+// Why.  Round 2's kernel (msda_fwd_pyr.hip) kept level 0 on the vector-memory path: 928 of its
+// 1 490 vector-memory instructions per workgroup were level-0 corner gathers, and the kernel sat
+// on that path's issue rate (profiles/r02_msda_fwd_pyr.md: 176 us per N=4 call, 0.227 of the HBM
+// line).  LDS serves ds_read_b128 at 256 B/clk/CU -- six times the vector-memory path -- so every
+// corner row now comes out of LDS and the vector-memory path only carries what is streamed once:
+// the window fills (LDS-DMA), the sampling locations / weights and the output.
+//
+// Decomposition (host plan: msda_pyr2.h).  The image plane is cut into regions; a 384-thread
+// workgroup -- TWO per CU, 80 KB of LDS each: while one fills its windows the other gathers, so the
+// vector-memory path and the LDS / VALU pipes overlap without software pipelining -- owns one
+// (image, region, head): all queries whose reference point lies in the region, in all four levels.
+// It works through PHASES that re-use one window buffer: stage the windows of the phase's levels
+// by LDS-DMA (`buffer_load_dwordx4 ... lds`, zero-fill outside the image), barrier, every task
+// (16 queries of one wave) gathers its samples of those levels, barrier.  The 16 x 128-B output
+// rows of a task stay in registers across the phases (kTPW tasks per wave, statically unrolled).
+// Window extents come from a per-(head, level) offset ENVELOPE: a DINO encoder's heads each look
+// in one direction, so a head's windows are about half the symmetric ones and level 0 fits.
+// A sample outside its window is fetched from global memory by a slow path: results never depend
+// on the plan.
+//
+// Lane mapping as in round 2: 4 lanes share a query; lane j works out the geometry of POINT j of
+// the level at hand and owns the 16-B pieces j and j + 4 of every 128-B row; geometry travels by
+// DPP quad broadcasts.  Which half a quad reads first alternates with bit 2 of its slot: the four
+// quads a ds_read_b128 serves together then hit four different 16-bank quarters for the common
+// access patterns (consecutive queries -> consecutive or pairwise-equal rows; exhaustive search of
+// the 256 assignments in DESIGN.md 4.1: 1.19 LDS cycles per group against 1.45 for round 2's
+// slot-parity rule).  The 4-corner blend is v_pk_fma_f32 on register pairs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "datr_hip.h"
+#include "msda_pyr2.h"
+
+// Development only: compile pieces out to see what they cost (results are wrong with a bit set).
+// 1 = no window fill, 4 = no LDS gathers, 8 = no loc/attn loads, 16 = no output stores, 32 = no blend FMAs,
+// 64 = no level loop at all (launch + prologue only), 128 = no barriers
+#ifndef PYR2_ABLATE
+#define PYR2_ABLATE 0
+#endif
+#ifndef PYR2_LDS_DEPTH
+#define PYR2_LDS_DEPTH 1          // samples whose corner rows are in flight out of LDS
+#endif
+
+#ifdef PYR2_PROBE
+// per-phase cycle counters of lane 0 of every wave (development; tools/probes/pyr2_ablate.sh)
+__device__ unsigned long long pyr2_phase_cycles[1024][8];   // many sets: one hot address would serialise
+__device__ unsigned long long pyr2_wg_span[8192][4];        // per workgroup: realtime start / end (100 MHz), cycles, XCC|CU id
+extern "C" void datr_probe_pyr2_wg_spans(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pyr2_wg_span), sizeof(pyr2_wg_span));
+}
+#define TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                     ticks_[i] += now_ - tick_; tick_ = now_; } while (0)
+extern "C" void datr_probe_pyr2_phase_cycles(unsigned long long *out, int reset) {
+    static unsigned long long all[1024][8];
+    (void)hipMemcpyFromSymbol(all, HIP_SYMBOL(pyr2_phase_cycles), sizeof(all));
+    for (int i = 0; i < 8; ++i) {
+        out[i] = 0;
+        for (int b = 0; b < 1024; ++b) out[i] += all[b][i];
+    }
+    if (reset) {
+        static unsigned long long z[1024][8];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pyr2_phase_cycles), z, sizeof(z));
+    }
+}
+#else
+#define TICK(i) do {} while (0)
+#endif
+
+namespace {
+
+constexpr unsigned kOutOfRange = 0x80000000u;    // >= num_records of every descriptor built here
+constexpr int kRowBytes = 128;                   // D = 32 floats
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f4 lds_f4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ f4 load_row4(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    // NB: keep `auto` -- converting the builtin's result to an ext_vector typedef splats lane 0.
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    static_assert(sizeof(r) == 16, "b128");
+    return __builtin_bit_cast(f4, r);
+}
+
+// broadcast lane `SRC` of every quad to the 4 lanes of the quad (DPP quad_perm [s,s,s,s])
+template <int SRC>
+__device__ __forceinline__ int quad_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, SRC * 0x55, 0xF, 0xF, true);
+}
+template <int SRC>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, quad_bcast<SRC>(__builtin_bit_cast(int, v)));
+}
+
+// acc (two channel pairs) += w * v with packed FMAs: 2 instructions per 16-B piece
+__device__ __forceinline__ void pk_fma4(f4 &acc, float w, const f4 v) {
+    f2 lo = {acc.x, acc.y}, hi = {acc.z, acc.w};
+    const f2 ww = {w, w};
+    lo = __builtin_elementwise_fma(ww, f2{v.x, v.y}, lo);
+    hi = __builtin_elementwise_fma(ww, f2{v.z, v.w}, hi);
+    acc = f4{lo.x, lo.y, hi.x, hi.y};
+}
+
+#define PIN(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
+
+struct Rows { f4 a[4], b[4]; };      // the lane's two 16-B pieces of the 4 corner rows of a sample
+
+// Window sample whose top-left LDS address lane SRC holds; row_bytes = window width * 128.
+template <int SRC>
+__device__ __forceinline__ void fetch_lds(Rows &r, const int base, const int chan, const int row_bytes) {
+    const int t1 = quad_bcast<SRC>(base) + chan, t2 = t1 ^ 64;
+    const int u1 = t1 + row_bytes, u2 = t2 + row_bytes;
+    if (PYR2_ABLATE & 4) {
+        r.a[0] = r.a[1] = r.b[0] = r.b[1] = f4{__builtin_bit_cast(float, t1 ^ t2), 0.f, 0.f, 0.f};
+        r.a[2] = r.a[3] = r.b[2] = r.b[3] = f4{__builtin_bit_cast(float, u1 ^ u2), 0.f, 0.f, 0.f};
+        return;
+    }
+    // the addresses ARE LDS addresses: the dynamic LDS block starts at 0 (no static LDS here);
+    // the right-hand corners are the next 128-B row: an immediate offset
+    r.a[0] = *reinterpret_cast<const lds_f4 *>((unsigned)t1);
+    r.b[0] = *reinterpret_cast<const lds_f4 *>((unsigned)t2);
+    r.a[1] = *reinterpret_cast<const lds_f4 *>((unsigned)t1 + kRowBytes);
+    r.b[1] = *reinterpret_cast<const lds_f4 *>((unsigned)t2 + kRowBytes);
+    r.a[2] = *reinterpret_cast<const lds_f4 *>((unsigned)u1);
+    r.b[2] = *reinterpret_cast<const lds_f4 *>((unsigned)u2);
+    r.a[3] = *reinterpret_cast<const lds_f4 *>((unsigned)u1 + kRowBytes);
+    r.b[3] = *reinterpret_cast<const lds_f4 *>((unsigned)u2 + kRowBytes);
+}
+
+// `first` = the piece the lane's t1 address points at (acc of the lane's FIRST read): the caller
+// passes (accA, accB) in read order, so no select is needed here.
+template <int SRC>
+__device__ __forceinline__ void accumulate(f4 &accA, f4 &accB, const Rows &r, const float (&w)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wk = quad_bcast<SRC>(w[k]);
+        if (PYR2_ABLATE & 32) {                  // no blend: one add keeps the dependency
+            accA.x += wk * r.a[k].x;
+            accB.x += r.b[k].x;
+            continue;
+        }
+        pk_fma4(accA, wk, r.a[k]);
+        pk_fma4(accB, wk, r.b[k]);
+    }
+}
+
+// The four points of one level (point p's geometry sits in lane p of the quad).
+__device__ __forceinline__ void lds_level(f4 &accA, f4 &accB, const int base, const float (&w)[4],
+                                          const int chan, const int row_bytes) {
+#if PYR2_LDS_DEPTH == 1
+    Rows r;
+    fetch_lds<0>(r, base, chan, row_bytes);
+    accumulate<0>(accA, accB, r, w);
+    PIN(accA, accB);
+    fetch_lds<1>(r, base, chan, row_bytes);
+    accumulate<1>(accA, accB, r, w);
+    PIN(accA, accB);
+    fetch_lds<2>(r, base, chan, row_bytes);
+    accumulate<2>(accA, accB, r, w);
+    PIN(accA, accB);
+    fetch_lds<3>(r, base, chan, row_bytes);
+    accumulate<3>(accA, accB, r, w);
+#else
+    Rows r0, r1;
+    fetch_lds<0>(r0, base, chan, row_bytes);
+    fetch_lds<1>(r1, base, chan, row_bytes);
+    PIN(accA, accB);
+    accumulate<0>(accA, accB, r0, w);
+    fetch_lds<2>(r0, base, chan, row_bytes);
+    PIN(accA, accB);
+    accumulate<1>(accA, accB, r1, w);
+    fetch_lds<3>(r1, base, chan, row_bytes);
+    PIN(accA, accB);
+    accumulate<2>(accA, accB, r0, w);
+    PIN(accA, accB);
+    accumulate<3>(accA, accB, r1, w);
+#endif
+}
+
+// pixel coordinates of a sample: floor, fractions, in-range test of cuh:285-288
+struct Pix { int iy, ix; float lh, lw; bool inside; };
+__device__ __forceinline__ Pix locate(float x, float y, int H, int W) {
+    Pix r;
+    const float Hf = (float)H, Wf = (float)W;
+    const float h_im = y * Hf - 0.5f, w_im = x * Wf - 0.5f;
+    r.inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    r.lh = h_im - hf;
+    r.lw = w_im - wf;
+    r.iy = r.inside ? (int)hf : 0;
+    r.ix = r.inside ? (int)wf : 0;
+    return r;
+}
+__device__ __forceinline__ void corner_weights(float (&w)[4], const Pix &p, float a) {
+    const float hh = 1.f - p.lh, hw = 1.f - p.lw;
+    const float ah = a * hh, al = a * p.lh;
+    w[0] = ah * hw;
+    w[1] = ah * p.lw;
+    w[2] = al * hw;
+    w[3] = al * p.lw;
+}
+
+template <int kTPW>
+__global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void msda_fwd_pyr2_d32(
+    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
+    const Pyr2Meta pm, int S, int M, int nimg, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int nreg = pm.nRy * pm.nRx;
+    const unsigned row_stride = (unsigned)M * kRowBytes;           // bytes between pixels of one head
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+    const int item = blockIdx.x;      // one (image, region, head) item per workgroup, head fastest:
+                                      // workgroup b runs on XCD b % 8, an XCD's L2 holds one head's slice
+    const int m = item % M;
+    const int reg = (item / M) % nreg;
+    const int n = item / (M * nreg);
+    const int ry = reg / pm.nRx, rx = reg % pm.nRx;
+
+    const float *base = value + ((size_t)n * S * M + m) * 32;
+    const int records = (S * M - m) * kRowBytes;                   // bytes from `base` to the end of item n
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, records, 0x00020000);
+
+    // ---- everything the workgroup needs from the plan, fetched ONCE as wide scalar loads --------
+    // (wave-uniform indices m, ry, rx; the level loops below are fully unrolled, so these stay in
+    // SGPRs and no load or wait sits between the gathers)
+    struct Lv { int H, W, start, WH, WW, lbase, wy0, wx0; } lv[4];
+    int pre[5], qoy[4], qox[4], qrw[4];
+    pre[0] = 0;
+    {
+        const int4v ya = *reinterpret_cast<const int4v *>(pm.yb[ry]), yb_ = *reinterpret_cast<const int4v *>(pm.yb[ry + 1]);
+        const int4v xa = *reinterpret_cast<const int4v *>(pm.xb[rx]), xb_ = *reinterpret_cast<const int4v *>(pm.xb[rx + 1]);
+        const int2v wyp = *reinterpret_cast<const int2v *>(pm.wy0[m][ry]);
+        const int2v wxp = *reinterpret_cast<const int2v *>(pm.wx0[m][rx]);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int4v h = *reinterpret_cast<const int4v *>(&pm.hl[m][l]);
+            lv[l].H = pm.H[l]; lv[l].W = pm.W[l]; lv[l].start = pm.start[l];
+            lv[l].WH = h.x; lv[l].WW = h.y; lv[l].lbase = h.z * kRowBytes;
+            const int wy2 = l < 2 ? wyp.x : wyp.y, wx2 = l < 2 ? wxp.x : wxp.y;
+            lv[l].wy0 = (l & 1) ? (wy2 >> 16) : (int)(short)(wy2 & 0xffff);
+            lv[l].wx0 = (l & 1) ? (wx2 >> 16) : (int)(short)(wx2 & 0xffff);
+            pre[l + 1] = pre[l] + (yb_[l] - ya[l]) * (xb_[l] - xa[l]);
+        }
+        // the region's queries: level by level, row by row of the region's footprint
+        qoy[0] = ya.x; qoy[1] = ya.y; qoy[2] = ya.z; qoy[3] = ya.w;
+        qox[0] = xa.x; qox[1] = xa.y; qox[2] = xa.z; qox[3] = xa.w;
+        qrw[0] = xb_.x - xa.x; qrw[1] = xb_.y - xa.y; qrw[2] = xb_.z - xa.z; qrw[3] = xb_.w - xa.w;
+    }
+    const int nq = pre[4];
+    const int ntasks = (nq + 15) >> 4;
+    const int nph = pm.nph;
+    const int4v phm = *reinterpret_cast<const int4v *>(pm.ph_mask);
+
+    // Lane roles.  4 lanes share a query; lane j owns the 16-B pieces j and j + 4 of every row and
+    // works out the geometry of POINT j.  Quads whose slot has bit 2 set read the upper half first.
+    const int slot = lane >> 2, j = lane & 3;
+    const int upper_first = (slot >> 2) & 1;
+    const int chan = 16 * j + 64 * upper_first;                    // byte offset of the FIRST read
+
+    // sampling locations / attention weights through buffer descriptors with 32-bit offsets
+    // (host-checked: N * Lq * M * 16 samples * 8 B < 2^31)
+    const __amdgpu_buffer_rsrc_t loc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(loc), 0, nimg * S * M * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t attn_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(attn), 0, nimg * S * M * 64, 0x00020000);
+
+    f4 accA[kTPW], accB[kTPW];                                     // read order: A = first read
+    int soff[kTPW];                                                // first sample index of the task's (query, head)
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) {
+        accA[t] = accB[t] = f4{0.f, 0.f, 0.f, 0.f};
+        int qi = (wave + t * kP2Waves) * 16 + slot;
+        qi = qi < nq ? qi : nq - 1;
+        const int lq = (qi >= pre[1]) + (qi >= pre[2]) + (qi >= pre[3]);
+        const int li = qi - (lq == 0 ? 0 : lq == 1 ? pre[1] : lq == 2 ? pre[2] : pre[3]);
+        const int oy = lq == 0 ? qoy[0] : lq == 1 ? qoy[1] : lq == 2 ? qoy[2] : qoy[3];
+        const int ox = lq == 0 ? qox[0] : lq == 1 ? qox[1] : lq == 2 ? qox[2] : qox[3];
+        const int rw = lq == 0 ? qrw[0] : lq == 1 ? qrw[1] : lq == 2 ? qrw[2] : qrw[3];
+        const int Wq = lq == 0 ? lv[0].W : lq == 1 ? lv[1].W : lq == 2 ? lv[2].W : lv[3].W;
+        const int sq = lq == 0 ? lv[0].start : lq == 1 ? lv[1].start : lq == 2 ? lv[2].start : lv[3].start;
+        const int r_ = (int)(((float)li + 0.5f) / (float)rw);
+        const int q = sq + (oy + r_) * Wq + ox + (li - r_ * rw);
+        soff[t] = ((n * S + q) * M + m) * 16;
+    }
+    struct LocW { f2 xy; float a; };
+    auto load_sample = [&](int so, int l) {
+        LocW r;
+#if PYR2_ABLATE & 8
+        // no loads: the centre of the level's window (always inside it), constant weight
+        r.xy = f2{((float)(lv[l].wx0 + lv[l].WW / 2) + 0.5f + 1e-9f * (float)so) / (float)lv[l].W,
+                  ((float)(lv[l].wy0 + lv[l].WH / 2) + 0.5f) / (float)lv[l].H};
+        r.a = 0.0625f;
+#else
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(loc_rsrc, (so + 4 * l + j) * 8, 0, 2);
+        r.xy = __builtin_bit_cast(f2, v);
+        r.a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(attn_rsrc, (so + 4 * l + j) * 4, 0, 2));
+#endif
+        return r;
+    };
+    // Memory-level parallelism: a level's locations / weights of ALL of the wave's tasks are
+    // requested one level ahead (4 x 768 B per wave, ~36 KB per CU in flight).
+    LocW cur[kTPW], nxt[kTPW];
+    auto load_level = [&](LocW (&dst)[kTPW], int l) {
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t)
+            if (wave + t * kP2Waves < ntasks) dst[t] = load_sample(soff[t], l);
+    };
+    load_level(nxt, 0);
+    TICK(0);                                             // prologue: plan loads, query decode
+
+    int next_phase = 0;
+#pragma unroll
+    for (int l = 0; l < ((PYR2_ABLATE & 64) ? 0 : 4); ++l) {
+        // ---- a new phase starts with level l: stage the windows of its levels by LDS-DMA --------
+        // One wave instruction moves 64 x 16 B = 8 window pixels straight into LDS; lane i lands at
+        // base + 16 i.  An out-of-image pixel gets an out-of-range offset: the load returns zeros.
+        const int mask = next_phase == 0 ? phm.x : next_phase == 1 ? phm.y : next_phase == 2 ? phm.z : phm.w;
+        if (next_phase < nph && (mask & ((1 << l) - 1)) == 0 && ((mask >> l) & 1)) {
+            if (next_phase > 0 && !(PYR2_ABLATE & 128)) __syncthreads();   // everyone is done with the old windows
+            TICK(1);                                     // waiting for the workgroup before a re-fill
+            ++next_phase;
+            if (!(PYR2_ABLATE & 1)) {
+#pragma unroll
+                for (int lf = l; lf < 4; ++lf) {
+                    if (!((mask >> lf) & 1)) continue;
+                    const int WW = lv[lf].WW, cnt = lv[lf].WH * WW * 8;
+                    const int wy0 = lv[lf].wy0, wx0 = lv[lf].wx0;
+                    const int Hl = lv[lf].H, Wl = lv[lf].W, st = lv[lf].start;
+                    const float inv = 1.0f / (float)WW;
+                    const int lbase = lv[lf].lbase;
+                    for (int i0 = wave * 64; i0 < cnt; i0 += kP2Threads) {
+                        const int i = i0 + lane;
+                        const int pix = i >> 3, chunk = i & 7;
+                        const int wr = (int)(((float)pix + 0.5f) * inv);
+                        const int wc = pix - wr * WW;
+                        const int y = wy0 + wr, x = wx0 + wc;
+                        const bool in = i < cnt && (unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl;
+                        const unsigned off = in ? (unsigned)(st + y * Wl + x) * row_stride + (unsigned)chunk * 16u
+                                                : kOutOfRange;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, reinterpret_cast<lds_void *>(lbase + i0 * 16),
+                                                                 16, (int)off, 0, 0, 0);
+                    }
+                }
+            }
+            TICK(2);                                     // fill issue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TICK(3);                                     // own fill pieces (and pending locations) landing
+            if (!(PYR2_ABLATE & 128)) __syncthreads();
+            TICK(4);                                     // waiting for the workgroup's pieces
+        }
+
+        const int Hl = lv[l].H, Wl = lv[l].W;
+        const int WW = lv[l].WW, WH = lv[l].WH;
+        const int wy0 = lv[l].wy0, wx0 = lv[l].wx0;
+        const int lbase = lv[l].lbase;
+        const int row_bytes = WW * kRowBytes;
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) cur[t] = nxt[t];
+#ifdef PYR2_PROBE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TICK(5);                                         // locations of this level landing
+        if (l + 1 < 4) load_level(nxt, l + 1);
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) {
+            const int ti = wave + t * kP2Waves;
+            if (ti >= ntasks) break;
+            const Pix p = locate(cur[t].xy.x, cur[t].xy.y, Hl, Wl);
+            const int wy = p.iy - wy0, wx = p.ix - wx0;
+            const bool inwin = (unsigned)wy <= (unsigned)(WH - 2) && (unsigned)wx <= (unsigned)(WW - 2);
+            const bool use = p.inside && inwin;
+            const bool miss = p.inside && !inwin;
+            const int wb = lbase + ((inwin ? wy : 0) * WW + (inwin ? wx : 0)) * kRowBytes;
+            float w[4];
+            corner_weights(w, p, use ? cur[t].a : 0.f);
+            lds_level(accA[t], accB[t], wb, w, chan, row_bytes);
+
+            // ---- slow path (rare): samples outside their window come from global memory ----------
+            if (__builtin_amdgcn_ballot_w64(miss) != 0) {
+                const int stl = lv[l].start;
+                const bool top = p.iy >= 0, bot = p.iy + 1 <= Hl - 1, lef = p.ix >= 0, rig = p.ix + 1 <= Wl - 1;
+                const unsigned pix = (unsigned)(stl + p.iy * Wl + p.ix) * row_stride;
+                int g[4];
+                g[0] = (int)((miss && top && lef) ? pix : kOutOfRange);
+                g[1] = (int)((miss && top && rig) ? pix + row_stride : kOutOfRange);
+                g[2] = (int)((miss && bot && lef) ? pix + (unsigned)Wl * row_stride : kOutOfRange);
+                g[3] = (int)((miss && bot && rig) ? pix + (unsigned)(Wl + 1) * row_stride : kOutOfRange);
+                float wm[4];
+                corner_weights(wm, p, miss ? cur[t].a : 0.f);
+                auto one = [&](int flag, auto src) {
+                    constexpr int SRC = decltype(src)::value;
+                    // only the quads whose sample missed execute this (divergent branch: the
+                    // vector-memory path is charged per active lane)
+                    if (flag) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned o = (unsigned)quad_bcast<SRC>(g[k]);
+                            const float wk = quad_bcast<SRC>(wm[k]);
+                            const f4 ra = load_row4(rsrc, o + (unsigned)chan);
+                            const f4 rb = load_row4(rsrc, o + (unsigned)(chan ^ 64));
+                            pk_fma4(accA[t], wk, ra);
+                            pk_fma4(accB[t], wk, rb);
+                        }
+                    }
+                };
+                const int mi = miss ? 1 : 0;
+                one(quad_bcast<0>(mi), std::integral_constant<int, 0>{});
+                one(quad_bcast<1>(mi), std::integral_constant<int, 1>{});
+                one(quad_bcast<2>(mi), std::integral_constant<int, 2>{});
+                one(quad_bcast<3>(mi), std::integral_constant<int, 3>{});
+            }
+            // keep the tasks apart: hoisting the next task's gathers above this one's blend
+            // overflows the register file
+            PIN(accA[t], accB[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TICK(6);                                         // geometry + gathers + blend of the level
+    }
+
+    // ---- output rows ---------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) {
+        const int ti = wave + t * kP2Waves;
+        if (ti >= ntasks) break;
+        const bool live = ti * 16 + slot < nq;
+        if (live && (!(PYR2_ABLATE & 16) || accA[t].x == 123.456f)) {
+            float *dst = out + (size_t)soff[t] * 2;                // 16 samples <-> 32 output floats
+            __builtin_nontemporal_store(accA[t], reinterpret_cast<f4 *>(dst + (chan >> 2)));
+            __builtin_nontemporal_store(accB[t], reinterpret_cast<f4 *>(dst + ((chan ^ 64) >> 2)));
+        }
+    }
+    }
+#ifdef PYR2_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TICK(7);                                             // output stores
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&pyr2_phase_cycles[(blockIdx.x * kP2Waves + wave) & 1023][i], ticks_[i]);
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        pyr2_wg_span[blockIdx.x][0] = rt0_;
+        pyr2_wg_span[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        pyr2_wg_span[blockIdx.x][2] = __builtin_readcyclecounter() - cy0_;
+        pyr2_wg_span[blockIdx.x][3] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+    }
+#endif
+}
+
+template <int kTPW>
+int launch(const float *value, const float *loc, const float *attn, const Pyr2Meta &pm, int64_t N,
+           int64_t S, int64_t M, float *out, hipStream_t stream) {
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_fwd_pyr2_d32<kTPW>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    kP2LdsBytes) == hipSuccess;
+    if (!attr_ok) return DATR_EUNSUPPORTED;
+    const long blocks = (long)N * pm.nRy * pm.nRx * M;
+    if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
+    hipLaunchKernelGGL(msda_fwd_pyr2_d32<kTPW>, dim3((unsigned)blocks), dim3(kP2Threads),
+                       (size_t)kP2WindowRows * kRowBytes, stream, value, loc, attn, pm, (int)S,
+                       (int)M, (int)N, out);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+}  // namespace
+
+// Plan only (no launch): what the kernel would do for this geometry / envelope.
+// info[0..7] = {covered, nRy, nRx, phases, tasks per wave, workgroups per image, fill KiB per
+// workgroup (head 0), largest window rows of a phase (head 0)}.
+extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+                                                int64_t S, int64_t M, const float *envelope_host,
+                                                Pyr2Meta *pm_out, int32_t *info) {
+    Pyr2Envelope env;
+    if (envelope_host) memcpy(&env, envelope_host, sizeof(env));
+    else p2_symmetric_envelope(env, 4.5f);
+    for (int m_ = 0; m_ < kP2Heads; ++m_)
+        for (int l = 0; l < 4; ++l)
+            for (int k = 0; k < 4; k += 2) {
+                float &lo = env.v[m_][l][k], &hi = env.v[m_][l][k + 1];
+                if (!(lo == lo) || !(hi == hi) || lo > hi) { lo = -4.5f; hi = 4.5f; }
+                lo = std::max(lo, -24.f);
+                hi = std::min(hi, 24.f);
+            }
+    // The grid search costs ~1 ms of host time: plans are cached (geometry + envelope -> plan).
+    // The cache is the library's only mutable state; it is guarded and holds plain data.
+    struct Entry { int64_t sh[8], S, M; Pyr2Envelope env; Pyr2Meta pm; bool ok; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    Pyr2Meta pm;
+    bool ok = false, hit = false;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry &e : cache)
+            if (e.S == S && e.M == M && memcmp(e.sh, shapes_host, sizeof(e.sh)) == 0 &&
+                memcmp(&e.env, &env, sizeof(env)) == 0) {
+                pm = e.pm; ok = e.ok; hit = true;
+                break;
+            }
+    }
+    if (!hit) {
+        memset(&pm, 0, sizeof(pm));
+        static const char *force = getenv("DATR_MSDA_PYR2_REGIONS");
+        ok = build_pyr2_meta(pm, shapes_host, level_start_host, S, (int)M, env, force);
+        Entry e;
+        memcpy(e.sh, shapes_host, sizeof(e.sh));
+        e.S = S; e.M = M; e.env = env; e.pm = pm; e.ok = ok;
+        std::lock_guard<std::mutex> lock(mu);
+        if (cache.size() >= 64) cache.erase(cache.begin());
+        cache.push_back(e);
+    }
+    if (info) {
+        memset(info, 0, 8 * sizeof(int32_t));
+        if (ok) {
+            int fill = 0, big = 0;
+            for (int p = 0; p < pm.nph; ++p) {
+                int r = 0;
+                for (int l = 0; l < 4; ++l)
+                    if (pm.ph_mask[p] >> l & 1) r += (pm.hl[0][l].WH * pm.hl[0][l].WW + 7) & ~7;
+                fill += r;
+                big = std::max(big, r);
+            }
+            info[0] = 1; info[1] = pm.nRy; info[2] = pm.nRx; info[3] = pm.nph; info[4] = pm.tpw;
+            info[5] = pm.nRy * pm.nRx * (int)M; info[6] = fill / 8; info[7] = big;
+        }
+    }
+    if (ok && pm_out) *pm_out = pm;
+    return ok ? DATR_OK : DATR_EUNSUPPORTED;
+}
+
+// Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
+extern "C" int datr_internal_msda_fwd_pyr2_d32(
+    const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
+    const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *out, void *stream)
+{
+    if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || M > kP2Heads || N < 1) return DATR_EUNSUPPORTED;
+    Pyr2Meta pm;
+    const int rc = datr_internal_msda_fwd_pyr2_plan(shapes_host, level_start_host, S, M, envelope_host, &pm, nullptr);
+    if (rc != DATR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (pm.tpw) {
+        case 1: case 2: return launch<2>(value, loc, attn, pm, N, S, M, out, st);
+        case 3: if constexpr (kP2MaxTasks >= 3) return launch<3>(value, loc, attn, pm, N, S, M, out, st);
+        case 4: if constexpr (kP2MaxTasks >= 4) return launch<4>(value, loc, attn, pm, N, S, M, out, st);
+        case 5: case 6: if constexpr (kP2MaxTasks >= 6) return launch<6>(value, loc, attn, pm, N, S, M, out, st);
+        default: return DATR_EUNSUPPORTED;
+    }
+}

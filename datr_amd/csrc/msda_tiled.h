@@ -36,6 +36,18 @@ extern "C" int datr_internal_msda_fwd_pyr_d32(
     const int64_t *level_start_host, int64_t N, int64_t S, int64_t M, int64_t D, int64_t L,
     int64_t Lq, int64_t P, float *out, void *stream);
 
+// phased all-LDS forward (msda_fwd_pyr2.hip); envelope_host: float[8][4][4] or NULL
+extern "C" int datr_internal_msda_fwd_pyr2_d32(
+    const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
+    const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *out, void *stream);
+struct Pyr2Meta;
+extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+                                                int64_t S, int64_t M, const float *envelope_host,
+                                                Pyr2Meta *pm_out, int32_t *info);
+extern "C" int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+                                               int64_t S, int64_t M, int32_t *info);
+
 extern "C" int datr_internal_msda_bwd_pyr_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,

@@ -86,10 +86,35 @@ def _host_meta(shapes: torch.Tensor, lsi: torch.Tensor):
     return hit[0], hit[1]
 
 
+def pyramid_plan(spatial_shapes, level_start_index, N, M, D, P, envelope=None):
+    """What the pyramid-region kernels would do for an encoder call (Lq == S) of this geometry,
+    without launching anything: dict(forward=bool, grid=(nRy, nRx), phases, tasks_per_wave,
+    workgroups_per_image, fill_kib, backward=bool, backward_grid).  `datr_msda_pyramid_plan`."""
+    import numpy as np
+    shapes, lsi = _as_int64(spatial_shapes), _as_int64(level_start_index)
+    sh_host, ls_host = (shapes.cpu().numpy().copy(), lsi.cpu().numpy().copy()) if not shapes.is_cuda \
+        else _host_meta(shapes, lsi)
+    S = int((sh_host[:, 0] * sh_host[:, 1]).sum())
+    info = np.zeros(16, dtype=np.int32)
+    env = None if envelope is None else np.ascontiguousarray(envelope, dtype=np.float32)
+    assert env is None or env.shape == (8, 4, 4)
+    rc = _native.lib.datr_msda_pyramid_plan(sh_host.ctypes.data, ls_host.ctypes.data, N, S, M, D,
+                                            sh_host.shape[0], S, P, None if env is None else env.ctypes.data,
+                                            info.ctypes.data)
+    _native.check(rc, "pyramid_plan")
+    return {"forward": bool(info[0]), "grid": (int(info[1]), int(info[2])), "phases": int(info[3]),
+            "tasks_per_wave": int(info[4]), "workgroups_per_image": int(info[5]), "fill_kib": int(info[6]),
+            "largest_phase_rows": int(info[7]), "phased": bool(info[11]), "backward": bool(info[8]),
+            "backward_grid": (int(info[9]), int(info[10]))}
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                           im2col_step: int, route: int = 0):
+                           im2col_step: int, route: int = 0, envelope=None):
     """-> Tensor [N, Lq, M*D]  (same contract as MSDA.ms_deform_attn_forward).
-    route (see OffsetMonitor): 0 = kernel by geometry; > 0 = no pyramid-region kernel."""
+    route (see OffsetMonitor): 0 = kernel by geometry; > 0 = no pyramid-region kernel.
+    envelope: optional numpy float32 [8, 4, 4] = per (head, level) {oy_lo, oy_hi, ox_lo, ox_hi}
+    in pixels, how far the samples lie from their reference points (a performance hint for the
+    phased pyramid kernel's window sizes; None = symmetric 4.5 px)."""
     for t, nme in ((value, "value"), (spatial_shapes, "spatial_shapes"),
                    (level_start_index, "level_start_index"), (sampling_loc, "sampling_loc"),
                    (attn_weight, "attn_weight")):
@@ -107,9 +132,10 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         if sfx == "f32" and D == 32 and Lq == S and L == 4 and P == 4 and PYR_FORWARD and route == 0:
             # encoder self-attention: pyramid-region forward, coarse-level windows staged in LDS
             sh_host, ls_host = _host_meta(shapes, lsi)
-            rc = _native.lib.datr_msda_forward_tiled_f32(
+            rc = _native.lib.datr_msda_forward_pyramid_f32(
                 value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), sh_host.ctypes.data,
-                ls_host.ctypes.data, sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                ls_host.ctypes.data, None if envelope is None else envelope.ctypes.data,
+                sampling_loc.data_ptr(), attn_weight.data_ptr(),
                 N, S, M, D, L, Lq, P, out.data_ptr(), stream)
         else:
             fn = getattr(_native.lib, f"datr_msda_forward_{sfx}")
@@ -158,10 +184,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
 class MSDeformAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                attention_weights, im2col_step, route=0):
+                attention_weights, im2col_step, route=0, envelope=None):
         ctx.im2col_step = im2col_step
         ctx.route = int(route)
         kw = {"route": ctx.route} if ctx.route else {}
+        if envelope is not None:
+            kw["envelope"] = envelope
         output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                         sampling_locations, attention_weights, ctx.im2col_step, **kw)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
@@ -175,7 +203,7 @@ class MSDeformAttnFunction(Function):
         kw = {"route": ctx.route} if ctx.route else {}
         grad_value, grad_loc, grad_attn = ms_deform_attn_backward(
             value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step, **kw)
-        return grad_value, None, None, grad_loc, grad_attn, None, None
+        return grad_value, None, None, grad_loc, grad_attn, None, None, None
 
 
 def _is_power_of_2(n: int) -> bool:
@@ -262,59 +290,110 @@ def _inverse_wh(spatial_shapes: torch.Tensor, n_heads: int, n_points: int) -> to
 
 
 class OffsetMonitor:
-    """Watches how far an encoder layer's sampling offsets reach and routes its MSDA calls.
+    """Watches where an encoder layer's samples fall relative to their queries and steers its MSDA
+    calls: the ROUTE (which kernel family) and the ENVELOPE (window sizes of the phased pyramid
+    forward, csrc/msda_fwd_pyr2.hip).
 
-    The pyramid-region kernels stage windows of footprint + 4.5 px and are the fastest choice while
-    nearly all samples stay inside (a DINO encoder: the ring initialisation reaches 4 px and training
-    moves the offsets by a few pixels); samples outside take a slow path, and with MANY outside the
-    other kernels win (N = 4 encoder call at 1333x800, forward / backward in us,
-    tools/bench_msda.py):   offsets ~ N(0, s px)    pyramid      row fwd / query-tiled bwd    row bwd
-                                 s = 1.5             180 /  994        239 / 1160               -
-                                 s = 2.5             223 / 1416        252 / 1362             4642
-                                 s = 4               327 / 2788        249 / 2462             4178
-                                 s = 6               373 / 7107        249 / 5191             3645
-                                 uniform             530 / 51238       272 / 11461            4668
-    Every `every`-th call the fraction f of (sub-sampled) samples whose offset exceeds the halo in
-    x or y is computed on the device and copied to pinned memory without synchronising; the call
-    `LAG` calls later -- a fixed count, so the step at which a route flips does not depend on host /
-    GPU timing and runs are reproducible; by then the copy completed long ago and the event wait
-    returns at once -- updates the route: f < 0.25 -> 0 (pyramid), f < 0.62 -> 1 (row forward,
-    query-tiled backward), else 2 (row kernels).  `DATR_MSDA_ADAPTIVE=0` pins route 0."""
+    Every `every`-th call, on a sub-sample of the queries, the displacement d of every sample from
+    its query's own pixel centre (mapped into the sampled level) is measured in pixels of that level:
+      * envelope[m, l] = the 0.5 % .. 99.5 % range of d_y and d_x over the samples of head m in
+        level l, widened by 0.25 px and clipped to +-8 px.  A DINO encoder's heads look in one
+        direction each (ring initialisation, ops/modules/ms_deform_attn.py:59-68), so these boxes
+        are a fraction of the symmetric halo; a padded batch's valid-ratio shift of the reference
+        points (deformable_transformer.py:524-533) is part of d and widens them as needed.
+      * fraction = share of samples with |d| > 4.5 px in x or y; route: f < 0.25 -> 0 (pyramid
+        kernels), f < 0.62 -> 1 (row forward, query-tiled backward), else 2 (row kernels) --
+        N = 4 encoder call at 1333x800, forward / backward in us for offsets ~ N(0, s px)
+        (round 2 kernels, tools/bench_msda.py):
+                                 s = 1.5   pyramid 180 /  994    rows+tiled 239 / 1160
+                                 s = 4             327 / 2788               249 / 2462
+                                 uniform           530 / 51238              272 / 11461   rows 272 / 4668
+    The numbers travel to pinned memory without a host synchronisation and are applied by the call
+    `LAG` calls later -- a fixed count, so the step at which a route or window plan changes does not
+    depend on host / GPU timing and runs are reproducible (the event wait then returns at once).
+    Results never depend on either: out-of-window samples take the kernels' slow paths."""
 
     HALO_PX = 4.5
-    LAG = 8                 # calls between a measurement and its use (>= one training step's worth)
+    LAG = 2                 # calls between a measurement and its use
+    MARGIN_PX = 0.25
+    CLIP_PX = 8.0
 
     def __init__(self, every: int = 50):
         self.every, self.calls, self.route, self.fraction = every, 0, 0, 0.0
+        self.envelope = None                     # numpy float32 [8, 4, 4] once measured
         self._pending = None
+        self._centres = {}
 
     @staticmethod
     def route_for(fraction: float) -> int:
         return 0 if fraction < 0.25 else (1 if fraction < 0.62 else 2)
 
     def poll(self):
-        if self._pending is not None and self.calls >= self._pending[2] + self.LAG:
-            self._pending[1].synchronize()
-            self.fraction = float(self._pending[0][0])
+        if self._pending is not None and self.calls + 1 >= self._pending[2] + self.LAG:   # this is call no. calls + 1
+            host, ev, _ = self._pending
+            ev.synchronize()
+            self.fraction = float(host[0])
             self.route = self.route_for(self.fraction)
+            if host.numel() == 1 + 128:
+                import numpy as np
+                self.envelope = np.ascontiguousarray(host[1:].numpy().reshape(8, 4, 4).copy())
             self._pending = None
         return self.route
 
-    def observe(self, offsets_norm: torch.Tensor, inv_wh: torch.Tensor):
-        """offsets_norm [N, Lq, 256]: offsets in units of the level's width / height (x, y
-        interleaved); inv_wh [256] = 1 / (W_l or H_l) per column."""
+    def _query_centres(self, shapes_host, stride, device):
+        """[S', 2] (x, y) pixel centres of every `stride`-th pyramid pixel, normalised to [0, 1]."""
+        key = (tuple(map(tuple, shapes_host.tolist())), stride, str(device))
+        hit = self._centres.get(key)
+        if hit is None:
+            refs = []
+            for h, w in shapes_host.tolist():
+                ys, xs = torch.meshgrid((torch.arange(h, dtype=torch.float32) + 0.5) / h,
+                                        (torch.arange(w, dtype=torch.float32) + 0.5) / w, indexing="ij")
+                refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+            hit = self._centres[key] = torch.cat(refs, 0)[::stride].contiguous().to(device)
+            if len(self._centres) > 8:
+                self._centres = {key: hit}
+        return hit
+
+    def measure(self, locations: torch.Tensor, shapes_host) -> torch.Tensor:
+        """Device tensor [1 + 128] (or [1]): fraction beyond the halo, then the envelope."""
+        N, S, M, L, P, _ = locations.shape
+        stride = max(1, S // 512)
+        ref = self._query_centres(shapes_host, stride, locations.device)
+        wh = torch.tensor([[w, h] for h, w in shapes_host.tolist()], dtype=torch.float32,
+                          device=locations.device).view(1, 1, 1, L, 1, 2)
+        d = (locations.detach()[:, ::stride] - ref.view(1, -1, 1, 1, 1, 2)) * wh    # px, (x, y)
+        far = (d.abs() > self.HALO_PX).any(-1).float().mean().view(1)
+        if (M, L) != (8, 4):
+            return far
+        v = d.permute(2, 3, 5, 0, 1, 4).reshape(M, L, 2, -1)                    # [m, l, (x, y), samples]
+        q = torch.quantile(v, torch.tensor([0.005, 0.995], device=v.device), dim=-1)   # [2, m, l, 2]
+        lo = (q[0] - self.MARGIN_PX).clamp(-self.CLIP_PX, self.CLIP_PX)
+        hi = (q[1] + self.MARGIN_PX).clamp(-self.CLIP_PX, self.CLIP_PX)
+        env = torch.stack([lo[..., 1], hi[..., 1], lo[..., 0], hi[..., 0]], -1)   # oy_lo, oy_hi, ox_lo, ox_hi
+        return torch.cat([far, env.reshape(-1)])
+
+    def observe(self, locations: torch.Tensor, shapes_host):
+        """locations [N, S, M, L, P, 2] normalised (x, y) of an encoder call (the queries are the
+        pyramid's own pixels, in pyramid order); shapes_host: numpy int64 [L, 2] (H, W)."""
         self.calls += 1
         if self._pending is not None or (self.calls - 1) % self.every:
             return
         with torch.no_grad():
-            stride = max(1, offsets_norm.shape[1] // 512)
-            px = offsets_norm.detach()[:, ::stride].abs() / inv_wh
-            far = (px > self.HALO_PX).view(*px.shape[:-1], -1, 2).any(-1)
-            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-            host.copy_(far.float().mean().view(1), non_blocking=True)
+            res = self.measure(locations, shapes_host)
+            host = torch.empty(res.numel(), dtype=torch.float32, pin_memory=True)
+            host.copy_(res, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         self._pending = (host, ev, self.calls)
+
+
+def measure_envelope(locations: torch.Tensor, spatial_shapes: torch.Tensor):
+    """Synchronous form of OffsetMonitor's measurement (tools, tests): numpy float32 [8, 4, 4] or
+    None when the call is not an 8-head 4-level one."""
+    import numpy as np
+    res = OffsetMonitor().measure(locations, _as_int64(spatial_shapes).cpu().numpy()).cpu()
+    return None if res.numel() == 1 else np.ascontiguousarray(res[1:].numpy().reshape(8, 4, 4))
 
 
 _MONITORS = weakref.WeakKeyDictionary()            # module -> OffsetMonitor (not part of the module:
@@ -434,15 +513,17 @@ class MSDeformAttn(nn.Module):
                     and reference_points.shape[-1] in (2, 4) \
                     and (fold_wh or reference_points.shape[-1] == 4) and value.dtype == torch.float32:
                 locations, weights = _Prologue.apply(both, reference_points.float())
-                route = 0
+                route, envelope = 0, None
                 if fold_wh and ADAPTIVE_ROUTING and Len_q == Len_in:       # encoder self-attention
                     mon = _MONITORS.get(self)
                     if mon is None:
                         mon = _MONITORS[self] = OffsetMonitor()
                     route = mon.poll()
-                    mon.observe(both[..., :self.sampling_offsets.out_features], inv)
+                    envelope = mon.envelope
+                    mon.observe(locations, _host_meta(_as_int64(input_spatial_shapes),
+                                                      _as_int64(input_level_start_index))[0])
                 out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                                 locations, weights, self.im2col_step, route)
+                                                 locations, weights, self.im2col_step, route, envelope)
                 return self.output_proj(out)
             n_off = self.sampling_offsets.out_features
             off2, wts2 = _SplitLast.apply(both, n_off)

@@ -103,6 +103,33 @@ int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value
                                        int64_t L, int64_t Lq, int64_t P, float *grad_value,
                                        float *grad_loc, float *grad_attn, void *stream);
 
+/* Encoder self-attention forward, round 3 (csrc/msda_fwd_pyr2.hip): the same contract as
+ * datr_msda_forward_tiled_f32 plus an optional per-(head, level) OFFSET ENVELOPE on the host,
+ *   envelope_host[8][4][4] = {oy_lo, oy_hi, ox_lo, ox_hi} in pixels of the sampled level:
+ * how far this call's sampling locations lie from their query's reference point (the sums
+ * `reference_points + sampling_offsets / (W_l, H_l)` of
+ * /root/reference/models/dino/ops/modules/ms_deform_attn.py:102-108).  The kernel stages value
+ * windows of footprint + envelope per level in LDS and gathers ALL four levels from there; a
+ * sample outside the envelope is fetched from global memory instead, so the envelope is a
+ * performance hint only -- results never depend on it.  NULL = symmetric +-4.5 px (the reach of the
+ * module's initial offset ring -- with which, as with any envelope too wide for all four windows to
+ * fit one LDS phase, the call runs round 2's kernel: datr_msda_forward_tiled_f32).  Shapes the phased kernel does not cover (D != 32, L != 4, P != 4,
+ * Lq != S, M > 8) fall through to datr_msda_forward_tiled_f32. */
+int datr_msda_forward_pyramid_f32(const float *value, const int64_t *shapes,
+                                  const int64_t *level_start, const int64_t *shapes_host,
+                                  const int64_t *level_start_host, const float *envelope_host,
+                                  const float *loc, const float *attn, int64_t N, int64_t S, int64_t M,
+                                  int64_t D, int64_t L, int64_t Lq, int64_t P, float *out, void *stream);
+/* What the pyramid-region kernels would do for this call, without launching anything.
+ * info[16] (int32): [0] forward covered by the phased kernel, [1] nRy, [2] nRx region grid,
+ * [3] phases, [4] 16-query tasks per wave, [5] workgroups per image, [6] LDS fill KiB per workgroup
+ * (head 0), [7] largest phase in 128-B rows (head 0); [8] backward covered by the pyramid-region
+ * kernel, [9] nRy, [10] nRx; [11] datr_msda_forward_pyramid_f32 would run the phased kernel (it does
+ * when an envelope is given and all four windows fit one phase; otherwise round 2's kernel); rest 0. */
+int datr_msda_pyramid_plan(const int64_t *shapes_host, const int64_t *level_start_host, int64_t N,
+                           int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                           const float *envelope_host, int32_t *info);
+
 /* Double-precision twins (generic kernels; they exist so the reference's gradcheck-in-double
  * op test, /root/reference/models/dino/ops/test.py:63-86, can be restated). */
 int datr_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

@@ -190,8 +190,8 @@ def test_pyramid_region_forward_full_size_n4_against_oracle(M, O, dev, kind):
 @pytest.mark.parametrize("kind", ["ring", "gauss"])
 def test_encoder_backward_full_size_n4_against_oracle(M, O, dev, kind):
     """The backward launch of the training step's merged encoder pass -- N = 4, Lq = S = 22 223,
-    query-tiled kernel (csrc/msda_bwd_tiled.hip) -- against the C oracle on EVERY element
-    (the full-size call was only compared with the build's own fp64 kernels)."""
+    the pyramid-region sorted-scatter kernel (csrc/msda_bwd_pyr.hip, route 0 of
+    datr_msda_backward_tiled_f32) -- against the C oracle on EVERY element."""
     N, Mh, D, P = 4, 8, 32, 4
     value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, FULL_SHAPES, P, seed=31)
     S = value.shape[1]
@@ -205,6 +205,42 @@ def test_encoder_backward_full_size_n4_against_oracle(M, O, dev, kind):
     else:
         loc = pyramid_locs(FULL_SHAPES, N, Mh, P, 3.0, seed=33)
     go = torch.randn(N, S, Mh * D, generator=g)
+    out, gv, gl, ga = run_hip(M, dev, value, sh, lsi, loc, attn, go)
+    torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
+    rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
+    scale = float(rv.abs().max())
+    torch.testing.assert_close(gv, rv, rtol=1e-3, atol=1e-5 * scale)
+    torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
+    keep = off_grid(loc, sh)
+    torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
+
+
+# Cityscapes -> Foggy Cityscapes frames are 1024x2048 after the x1.5 scaling capped at 2048
+# (/root/reference/config/DA/Cityscapes2FoggyCityscapes/coco_transformer_C2F.py:1-7):
+# the pyramid the mAP clause of the north star would run at.
+C2F_SHAPES = [(128, 256), (64, 128), (32, 64), (16, 32)]
+
+
+@pytest.mark.parametrize("kind", ["ring", "gauss"])
+def test_c2f_geometry_forward_backward_against_oracle(M, O, dev, kind):
+    """The real C2F geometry (level 0 = 128 x 256, S = 43 520, N = 2: one source + one target image)
+    through the pyramid-region forward and backward kernels, every element against the C oracle:
+    a different region grid, different window sizes and different query-table sizes than the
+    1333x800 pyramid the other full-size tests use."""
+    N, Mh, D, P = 2, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, C2F_SHAPES, P, seed=41)
+    S = value.shape[1]
+    assert S == 43520
+    g = torch.Generator().manual_seed(42)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    if kind == "ring":
+        ring = M.MSDeformAttn(256, 4, Mh, P).sampling_offsets.bias.detach().view(1, 1, Mh, 4, P, 2)
+        wh = torch.tensor([[w, h] for h, w in C2F_SHAPES], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+        loc = (pyramid_locs(C2F_SHAPES, N, Mh, P, 0.05, seed=43) + ring / wh).contiguous()
+    else:
+        loc = pyramid_locs(C2F_SHAPES, N, Mh, P, 2.5, seed=43)
+    go = torch.randn(N, S, Mh * D, generator=g)
+    assert M.PYR_FORWARD
     out, gv, gl, ga = run_hip(M, dev, value, sh, lsi, loc, attn, go)
     torch.testing.assert_close(out, O.msda_forward(value, sh, lsi, loc, attn), **tol(torch.float32))
     rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
@@ -422,20 +458,123 @@ def test_routes_agree_and_the_offset_monitor_switches_them():
 
     def call():
         return mod(query, refpts, src, shapes, lsi)
-    y0 = call()
-    torch.cuda.synchronize()
+    y0 = call()                                                   # call 1: measures
     call()
+    call()                                                        # call 1 + LAG: the measurement is applied
     mon = msda._MONITORS[mod]
     assert mon.route == 0 and mon.fraction == 0.0                 # ring initialisation: nothing beyond 4 px
+    # the envelope the phased forward sizes its windows by: head 0 looks along +x only (1..4 px)
+    env = mon.envelope
+    assert env is not None and env.shape == (8, 4, 4) and env.dtype == np.float32
+    ring = mod.sampling_offsets.bias.detach().view(8, 4, 4, 2).cpu()
+    for h in range(8):
+        for l in range(4):
+            assert env[h, l, 0] <= float(ring[h, l, :, 1].min()) <= float(ring[h, l, :, 1].max()) <= env[h, l, 1]
+            assert env[h, l, 2] <= float(ring[h, l, :, 0].min()) <= float(ring[h, l, :, 0].max()) <= env[h, l, 3]
+            assert env[h, l, 1] - env[h, l, 0] <= 3.0 + 2 * mon.MARGIN_PX + 1e-3
+    assert msda.pyramid_plan(shapes, lsi, N, 8, 32, 4, env)["phased"]
+    y0b = call()                                                  # now through the phased kernel
+    torch.testing.assert_close(y0b, y0, rtol=1e-4, atol=1e-4)
     with torch.no_grad():
         mod.sampling_offsets.bias.mul_(2.5)                       # up to 10 px: most points leave the halo
     mon.calls = 0                                                 # next call probes again
     y1 = call()
-    torch.cuda.synchronize()
-    y2 = call()                                                   # finds the read-back complete
+    call()
+    y2 = call()                                                   # LAG calls later: new route
     assert mon.fraction > 0.5 and mon.route == msda.OffsetMonitor.route_for(mon.fraction) and mon.route > 0
     torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-4)      # route 0 vs the new route: same values
     assert y0.shape == y1.shape
+
+
+def _phased(M, dev, value, sh, lsi, loc, attn, envelope, force=False):
+    """The phased all-LDS forward (csrc/msda_fwd_pyr2.hip).  force: call the kernel's own entry even
+    where the public dispatch would prefer round 2's kernel (multi-phase plans)."""
+    from datr_amd import _native
+    v, s_, a = value.to(dev), loc.to(dev), attn.to(dev)
+    if not force:
+        return M.ms_deform_attn_forward(v, sh.to(dev), lsi.to(dev), s_, a, 64, envelope=envelope).cpu()
+    N, S, Mh, D = v.shape
+    out = torch.full((N, S, Mh * D), float("nan"), device=dev)
+    shh, lsh = sh.cpu().numpy().copy(), lsi.cpu().numpy().copy()
+    fn = _native.lib.datr_internal_msda_fwd_pyr2_d32
+    import ctypes
+    fn.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64] * 7 + [ctypes.c_void_p, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    rc = fn(v.data_ptr(), s_.data_ptr(), a.data_ptr(), shh.ctypes.data, lsh.ctypes.data,
+            None if envelope is None else envelope.ctypes.data, N, S, Mh, D, 4, S, 4, out.data_ptr(),
+            _native.current_stream_ptr(dev))
+    assert rc == 0, rc
+    return out.cpu()
+
+
+@pytest.mark.parametrize("shapes,spread,env_kind", [
+    ([(20, 27), (10, 14), (5, 7), (3, 4)], 1.5, "measured"),
+    ([(40, 61), (20, 31), (10, 16), (5, 8)], 1.0, "measured"),     # several regions per axis
+    ([(40, 61), (20, 31), (10, 16), (5, 8)], 4.0, "symmetric"),    # multi-phase plan, forced
+    ([(33, 50), (17, 25), (9, 13), (5, 7)], 6.0, "tight"),         # envelope far too small: slow path
+    ([(33, 50), (17, 25), (9, 13), (5, 7)], 3.0, "lopsided"),      # per-head directional envelopes
+    ([(64, 96), (32, 48), (16, 24), (8, 12)], 2.0, "measured"),
+])
+def test_phased_pyramid_forward_matches_oracle(M, O, dev, shapes, spread, env_kind):
+    """csrc/msda_fwd_pyr2.hip: all four levels out of LDS windows sized by a per-(head, level)
+    envelope.  Whatever the envelope says -- measured, symmetric, much too tight (every sample
+    through the global-memory slow path), lopsided per head -- the result equals the oracle's."""
+    N, Mh, D, P = 2, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, shapes, P, seed=13)
+    S = value.shape[1]
+    loc = pyramid_locs(shapes, N, Mh, P, spread, seed=7)
+    if env_kind == "lopsided":            # head m looks along direction m, like the ring initialisation
+        ring = M.MSDeformAttn(256, 4, Mh, P).sampling_offsets.bias.detach().view(1, 1, Mh, 4, P, 2)
+        wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+        loc = (pyramid_locs(shapes, N, Mh, P, 0.3, seed=7) + ring / wh).contiguous()
+    g = torch.Generator().manual_seed(8)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    if env_kind in ("measured", "lopsided"):
+        env = M.measure_envelope(loc.to(dev), sh)
+    elif env_kind == "symmetric":
+        env = None
+    else:
+        env = np.tile(np.array([-0.4, 0.4, -0.4, 0.4], np.float32), (8, 4, 1))
+    want = O.msda_forward(value, sh, lsi, loc, attn)
+    plan = M.pyramid_plan(sh, lsi, N, Mh, D, P, env)
+    assert plan["forward"]
+    if env_kind == "lopsided":
+        assert plan["phased"] and float((env[:, :, 1] - env[:, :, 0]).min()) < 2.5      # axis-aligned heads
+    out = _phased(M, dev, value, sh, lsi, loc, attn, env, force=True)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out, want, **tol(torch.float32))
+    torch.testing.assert_close(_phased(M, dev, value, sh, lsi, loc, attn, env), want, **tol(torch.float32))
+
+
+@pytest.mark.parametrize("geometry", ["1333x800", "c2f"])
+@pytest.mark.parametrize("kind", ["ring", "gauss", "border"])
+def test_phased_pyramid_forward_full_size_against_oracle(M, O, dev, geometry, kind):
+    """The launch the training step makes once the monitor has measured the envelope: N = 4 at the
+    1333x800 pyramid (N = 2 at the C2F geometry 128x256), every element against the C oracle.
+    `ring` is the one-phase plan of the phased kernel (asserted); `gauss` / `border` have wide
+    envelopes and go to whichever kernel the dispatch picks -- and are forced through the phased
+    kernel's multi-phase form as well."""
+    shapes = FULL_SHAPES if geometry == "1333x800" else C2F_SHAPES
+    N, Mh, D, P = (4 if geometry == "1333x800" else 2), 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, shapes, P, seed=21)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(22)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    if kind == "ring":
+        ring = M.MSDeformAttn(256, 4, Mh, P).sampling_offsets.bias.detach().view(1, 1, Mh, 4, P, 2)
+        wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+        loc = (pyramid_locs(shapes, N, Mh, P, 0.05, seed=23) + ring / wh).contiguous()
+    else:
+        loc = pyramid_locs(shapes, N, Mh, P, 2.0 if kind == "gauss" else 12.0, seed=23)
+    env = M.measure_envelope(loc.to(dev), sh)
+    plan = M.pyramid_plan(sh, lsi, N, Mh, D, P, env)
+    if kind == "ring":
+        assert plan["phased"] and plan["phases"] == 1, plan
+    want = O.msda_forward(value, sh, lsi, loc, attn)
+    torch.testing.assert_close(_phased(M, dev, value, sh, lsi, loc, attn, env), want, **tol(torch.float32))
+    if plan["forward"]:
+        torch.testing.assert_close(_phased(M, dev, value, sh, lsi, loc, attn, env, force=True), want,
+                                   **tol(torch.float32))
 
 
 def test_padded_rows_are_zeroed_in_place_like_masked_fill():

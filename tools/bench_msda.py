@@ -89,15 +89,25 @@ def main():
     ap.add_argument("--dist", default="both")
     ap.add_argument("--n", type=int, default=2, help="batch items per call (the training step merges source + target: 4)")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--encoder-only", action="store_true", help="only the Lq = S call")
+    ap.add_argument("--envelope", default="measured", choices=["none", "measured"],
+                    help="window envelope of the phased pyramid forward: measured from the locations "
+                         "(what datr_amd.msda.OffsetMonitor hands over in the model) or none (symmetric 4.5 px)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dists = ["uniform", "model"] if args.dist == "both" else [args.dist]
     for dist in dists:
-        for Lq in (22223, 1100, 900):
+        for Lq in ((22223,) if args.encoder_only else (22223, 1100, 900)):
             value, sh, lsi, loc, attn = make_inputs(dev, Lq, dist, N=args.n)
             N, S = value.shape[0], value.shape[1]
             go = torch.randn(N, Lq, 256, device=dev)
-            f = lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64)
+            env, plan = None, None
+            if Lq == S:
+                if args.envelope == "measured":
+                    env = msda.measure_envelope(loc, sh)
+                plan = msda.pyramid_plan(sh, lsi, N, 8, 32, 4, env)
+            kw = {} if env is None else {"envelope": env}
+            f = lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64, **kw)
             b = lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
             fm, fmin = time_fn(f, args.iters)
             bm, bmin = (0.0, 0.0) if args.fwd_only else time_fn(b, args.iters)
@@ -127,6 +137,39 @@ def main():
                     f"{n}={100 * v / tot:.1f}%" for n, v in zip(
                         ["fill-issue", "fill-land", "barrier", "locwait+geom", "gathers", "slow+store", "tail-wait"], buf)),
                     f"total={tot / 1e6:.1f} Mcycles")
+            if os.environ.get("PYR2_PROBE") and Lq == 22223:
+                import ctypes
+                from datr_amd import _native
+                buf = (ctypes.c_ulonglong * 8)()
+                _native.lib.datr_probe_pyr2_phase_cycles(buf, 1)
+                f()
+                torch.cuda.synchronize()
+                _native.lib.datr_probe_pyr2_phase_cycles(buf, 1)
+                tot = sum(buf) or 1
+                print("pyr2 phase cycles (lane 0 of every wave, one call): " + ", ".join(
+                    f"{n}={100 * v / tot:.1f}%" for n, v in zip(
+                        ["prologue", "refill-barrier", "fill-issue", "fill-land", "fill-barrier", "loc-land",
+                         "geom+gather+blend", "stores"], buf)),
+                    f"total={tot / 1e6:.1f} Mcycles")
+                import numpy as np
+                spans = np.zeros((8192, 4), dtype=np.uint64)
+                _native.lib.datr_probe_pyr2_wg_spans(spans.ctypes.data_as(ctypes.c_void_p))
+                nb = plan["workgroups_per_image"] * N
+                sp = spans[:min(nb, 8192)].astype(np.int64)
+                t0, t1 = sp[:, 0].min(), sp[:, 1].max()
+                dur = (sp[:, 1] - sp[:, 0]) / 100.0                      # us (100 MHz)
+                # concurrency over time
+                ev = np.concatenate([np.stack([sp[:, 0], np.ones(len(sp), np.int64)], 1),
+                                     np.stack([sp[:, 1], -np.ones(len(sp), np.int64)], 1)])
+                ev = ev[np.argsort(ev[:, 0], kind="stable")]
+                conc = np.cumsum(ev[:, 1])
+                dt = np.diff(ev[:, 0])
+                avg_conc = float((conc[:-1] * dt).sum() / max(1, dt.sum()))
+                clk = sp[:, 2] / np.maximum(dur, 1e-9) / 1e3                # GHz
+                cu = (sp[:, 3] >> 32) * 1000 + ((sp[:, 3] >> 8) & 0xf) * 16 + ((sp[:, 3] >> 13) & 0x7) * 100
+                print(f"wg spans: kernel {(t1 - t0) / 100.0:.1f} us, wg duration mean {dur.mean():.1f} us "
+                      f"(min {dur.min():.1f}, max {dur.max():.1f}), mean concurrency {avg_conc:.0f} workgroups "
+                      f"(peak {conc.max()}), shader clock {np.median(clk):.2f} GHz, distinct CU ids {len(np.unique(cu))}")
             if os.environ.get("PYR_PROBE_BWD") and Lq == 22223:
                 import ctypes
                 from datr_amd import _native
@@ -141,7 +184,7 @@ def main():
                         ["setup", "passA", "barrier+scan", "passB", "reduce+flush"], buf)),
                     f"total={tot / 1e6:.1f} Mcycles")
             print(json.dumps({
-                "dist": dist, "Lq": Lq, "N": N, "pyr_fwd": msda.PYR_FORWARD,
+                "dist": dist, "Lq": Lq, "N": N, "pyr_fwd": msda.PYR_FORWARD, "plan": plan,
                 "fwd_us_median": round(fm, 2), "fwd_us_min": round(fmin, 2),
                 "fwd_GBps": round(fwd_bytes(N, S, Lq) / fm / 1e3, 1),
                 "bwd_us_median": round(bm, 2), "bwd_us_min": round(bmin, 2),
