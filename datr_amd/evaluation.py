@@ -94,8 +94,11 @@ class BoxEvaluator:
         for img, p in predictions.items():
             img = int(img)
             boxes = p["boxes"].detach().float().cpu().numpy().reshape(-1, 4)
+            # width / height in float32 as the reference's convert_to_xywh does on the float32 tensors
+            # (datasets/coco_eval.py:252-254), then doubles: `.tolist()` there, and the C routine
+            # behind COCOeval's IoU works in double
             xywh = np.stack([boxes[:, 0], boxes[:, 1], boxes[:, 2] - boxes[:, 0],
-                             boxes[:, 3] - boxes[:, 1]], 1) if len(boxes) else np.zeros((0, 4))
+                             boxes[:, 3] - boxes[:, 1]], 1).astype(np.float64) if len(boxes) else np.zeros((0, 4))
             self.dt[img] = {"boxes": xywh,
                             "scores": p["scores"].detach().float().cpu().numpy().reshape(-1),
                             "labels": p["labels"].detach().cpu().numpy().reshape(-1).astype(np.int64)}

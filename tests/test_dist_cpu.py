@@ -319,3 +319,95 @@ def test_dino_epoch_function_world2_matches_single_process_gradients(tmp_path):
     port = _free_port()
     mp.spawn(_dino_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+# ---------------------------------------------------------------------------------------------
+# four ranks, the teacher-student epoch function, many buckets, rank-dependent pseudo labels
+# ---------------------------------------------------------------------------------------------
+def _selftrain_worker(rank, world, port, tmp):
+    import copy
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import synth
+    from helpers import build_model
+    from datr_amd import criterion as crit_mod, msda
+    from datr_amd.config import get_param_dict
+    from datr_amd.dist import GradAllReducer, attach_reducer, init_distributed, reducer_for
+    from datr_amd.ema import ModelEMA
+    from datr_amd.engine import train_one_epoch_with_self_training
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    from oracle import focal_oracle, msda_oracle as O
+    msda.ms_deform_attn_forward = lambda v, sh, lsi, loc, a, step: O.msda_forward(v, sh, lsi, loc, a)
+    msda.ms_deform_attn_backward = lambda v, sh, lsi, loc, a, go, step: \
+        list(O.msda_backward(v, sh, lsi, loc, a, go))
+    crit_mod.focal_loss_sums = focal_oracle.focal_sums_torch
+    init_distributed(backend="gloo")
+
+    args, model, criterion, _ = build_model()
+    # ranks 0 and 2 find pseudo labels, ranks 1 and 3 find none (threshold above every score):
+    # the target-domain criterion then returns {} there and fewer gradients are produced
+    args.pseudo_label_threshold = 0.02 if rank % 2 == 0 else 0.999
+    teacher = ModelEMA(model, decay=args.ema_decay_teacher)
+    red = GradAllReducer(model, bucket_mb=24.0, first_bucket_mb=2.0)
+    attach_reducer(model, red)
+    assert len(red.buckets) >= 6, len(red.buckets)
+    ref = copy.deepcopy(model)
+    attach_reducer(ref, False)
+    assert reducer_for(ref, args) is None and reducer_for(model, args) is red
+
+    imgs, targets = synth.synth_batch(seed=3 + rank, sizes=((192, 240), (184, 232)), num_gt=2 + rank % 2)
+    g = torch.Generator().manual_seed(50 + rank)
+    strong = [imgs[0], imgs[1] + 0.3 * torch.randn(imgs[1].shape, generator=g)]
+    meta = [{"image_id": torch.tensor([rank]), "orig_size": torch.tensor([368, 464]),
+             "size": torch.tensor([184, 232]), "boxes": torch.zeros(0, 4),
+             "labels": torch.zeros(0, dtype=torch.long)}]
+    loader = [(nested_tensor_from_tensor_list(imgs), tuple(targets), tuple(meta),
+               nested_tensor_from_tensor_list(strong))]
+
+    def run(m):
+        opt = torch.optim.SGD(get_param_dict(args, m), lr=0.0)        # gradients only
+        torch.manual_seed(200 + rank)                                  # CDN noise
+        return train_one_epoch_with_self_training(m, teacher, criterion, loader, loader, opt,
+                                                  torch.device("cpu"), 0, max_norm=0, args=args)
+    s_ref = run(ref)                     # single-process gradients of this rank's batch
+    s_red = run(model)                   # the same step with the reducer
+    assert s_ref["_last"]["num_pseudo_images"] == s_red["_last"]["num_pseudo_images"] == (1 if rank % 2 == 0 else 0)
+    n_pseudo = torch.tensor([s_red["_last"]["num_pseudo_images"]])
+    dist.all_reduce(n_pseudo)
+    assert int(n_pseudo) == 2, "two of the four ranks must have produced pseudo labels"
+    worst, missing = 0.0, 0
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if not p.requires_grad:
+            continue
+        missing += q.grad is None
+        local = torch.zeros_like(q) if q.grad is None else q.grad.clone()
+        dist.all_reduce(local)
+        local /= world
+        assert p.grad is not None, n
+        scale = float(local.abs().max()) + 1e-12
+        err = float((p.grad - local).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 1e-4, (n, err)
+    sizes = torch.tensor([b.numel for b in red.buckets])
+    dist.broadcast(sizes, 0)
+    assert sizes.tolist() == [b.numel for b in red.buckets], "bucket layout differs between ranks"
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write(f"ok {worst:.2e} buckets {len(red.buckets)} missing {missing}")
+
+
+def test_selftraining_epoch_function_world4_many_buckets_rank_dependent_pseudo_labels(tmp_path):
+    """four gloo ranks through `engine.train_one_epoch_with_self_training` with the
+    real detector (tiny images), >= 6 gradient buckets, and pseudo labels on ranks 0 / 2 only -- the
+    ranks without them skip the target-domain criterion and produce fewer gradients, yet every rank
+    issues the same collectives in the same order and ends with the average of the four
+    single-process gradients."""
+    port = _free_port()
+    mp.spawn(_selftrain_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(4))

@@ -38,3 +38,73 @@ def test_two_burn_in_steps_on_device():
     probe.check_final(stats, stat_rtol=5e-3, norm_rtol=1e-4, delta_cos=0.995, skip_counts=True)
     torch.testing.assert_close(model.global_proto.cpu(), t(g["global_proto"]), rtol=5e-3, atol=2e-3)
     torch.testing.assert_close(model.Amount.cpu(), t(g["Amount"]), rtol=0, atol=3.0)
+
+
+def test_evaluate_loop_on_device_matches_independent_protocol():
+    """SURVEY.md 8 f3 / VERDICT r2: `datr_amd.engine.evaluate` (counterpart of
+    /root/reference/engine.py:349-523) end to end on the device -- eval-mode forward, criterion for
+    the logged losses, PostProcess on the device, results keyed by image id, accumulate / summarize --
+    with the 12 COCO numbers checked against tests/coco_bruteforce.py (the independently written
+    protocol restatement) fed with the very detections the loop's post-processor produced.
+    Ground truth = the synthetic targets plus, so that the precision / recall curves are not
+    trivially zero, boxes taken from a first eval forward's own top detections (some shifted to
+    IoU ~0.6 / ~0.8, one marked crowd)."""
+    import numpy as np
+    import synth
+    import coco_bruteforce as bf
+    from datr_amd.detector import PostProcess
+    from datr_amd.engine import evaluate
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    dev = torch.device("cuda:0")
+    args, model, criterion, _ = build_model("cuda:0")
+    criterion.to(dev)
+    imgs, targets = synth.synth_batch()
+    imgs = [i.to(dev) for i in imgs]
+    sizes = torch.tensor([[480.0, 600.0], [360.0, 450.0]], device=dev)
+    post = PostProcess(num_select=100)
+    model.eval()
+    with torch.no_grad():
+        first = post(model(nested_tensor_from_tensor_list(imgs)), sizes)
+
+    def gt_from(res, k, img_id, size, shifts):
+        xyxy = res["boxes"][:k].clone()
+        for i, s in enumerate(shifts):
+            xyxy[i, [0, 2]] += s * (xyxy[i, 2] - xyxy[i, 0])
+        h, w = float(size[0]), float(size[1])
+        cx, cy = (xyxy[:, 0] + xyxy[:, 2]) / 2 / w, (xyxy[:, 1] + xyxy[:, 3]) / 2 / h
+        bw, bh = (xyxy[:, 2] - xyxy[:, 0]) / w, (xyxy[:, 3] - xyxy[:, 1]) / h
+        crowd = torch.zeros(k, dtype=torch.long, device=dev)
+        crowd[-1] = 1
+        return {"boxes": torch.stack([cx, cy, bw, bh], -1).clamp(0, 1), "labels": res["labels"][:k].clone(),
+                "image_id": torch.tensor([img_id], device=dev), "orig_size": size.clone(), "size": size.clone(),
+                "iscrowd": crowd}
+    tg = [gt_from(first[0], 6, 11, sizes[0], [0.0, 0.1, 0.25, 0.0, 0.5, 0.0]),
+          gt_from(first[1], 4, 12, sizes[1], [0.0, 0.25, 0.1, 0.0])]
+    recorded = []
+
+    class Recording(torch.nn.Module):
+        def forward(self, outputs, target_sizes):
+            res = post(outputs, target_sizes)
+            recorded.append([{k: v.detach().clone() for k, v in r.items()} for r in res])
+            return res
+    loader = [(nested_tensor_from_tensor_list(imgs), None, tuple(tg))]
+    args.use_dn = False
+    stats, evaluator = evaluate(model, criterion, {"bbox": Recording()}, loader, None, dev, args=args)
+    assert len(recorded) == 1 and all(r["boxes"].is_cuda for r in recorded[0])
+    coco = stats["coco_eval_bbox"]
+    assert len(coco) == 12 and "loss" in stats and "loss_ce_unscaled" in stats and np.isfinite(stats["loss"])
+    # the same detections through the independent restatement
+    gts, dts = {}, {}
+    for t_, res in zip(tg, recorded[0]):
+        img = int(t_["image_id"])
+        h, w = [float(v) for v in t_["orig_size"]]
+        b = t_["boxes"].float().cpu()
+        xywh = torch.stack([(b[:, 0] - b[:, 2] / 2) * w, (b[:, 1] - b[:, 3] / 2) * h, b[:, 2] * w, b[:, 3] * h], -1)
+        gts[img] = [(xywh[i].tolist(), int(t_["labels"][i]), int(t_["iscrowd"][i]), float(xywh[i, 2] * xywh[i, 3]))
+                    for i in range(len(b))]
+        bx = res["boxes"].float().cpu().numpy()
+        dts[img] = [([float(q[0]), float(q[1]), float(q[2] - q[0]), float(q[3] - q[1])], float(s), int(l))
+                    for q, s, l in zip(bx, res["scores"].cpu().numpy(), res["labels"].cpu().numpy())]
+    want = bf.coco_stats([11, 12], gts, dts)
+    assert np.allclose(coco, want, rtol=0, atol=1e-9), (coco, want)
+    assert coco[1] > 0.3 and coco[8] > 0.3          # the loop's own detections find the planted boxes

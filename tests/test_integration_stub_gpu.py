@@ -63,3 +63,52 @@ def test_documented_binding_runs_and_matches_the_oracle():
         torch.testing.assert_close(g.cpu(), w, rtol=1e-4, atol=1e-5)
     with pytest.raises(AssertionError):                      # CPU tensors are refused, as in the reference
         MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64)
+
+
+def test_documented_binding_reaches_the_product_kernels():
+    """the binding a maintainer is told to add must land on the kernels bench.py
+    measures, not on the row kernels.  An encoder call at the full 1333x800 geometry (N = 2): the plan
+    query says pyramid-region forward AND backward, the results equal the oracle's, and the backward
+    is far below what the row kernel needs for this call (9.7 ms at N = 4, profiles/r02_*): < 2.5 ms."""
+    from oracle import msda_oracle as O
+    MSDA = _load_stub()
+    dev = torch.device("cuda:0")
+    shapes_l = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    N, Mh, P = 2, 8, 4
+    value, shapes, lsi, _, _ = O.random_inputs(N, 1, Mh, 32, shapes_l, P, seed=5)
+    S = value.shape[1]
+    refs = []
+    for h, w in shapes_l:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    wh = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+    g = torch.Generator().manual_seed(6)
+    loc = (torch.cat(refs, 0).view(1, S, 1, 1, 1, 2) + torch.randn(N, S, Mh, 4, P, 2, generator=g) * 1.5 / wh).contiguous()
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    go = torch.randn(N, S, Mh * 32, generator=g)
+    d = [t.to(dev) for t in (value, shapes, lsi, loc, attn)]
+    info = MSDA.pyramid_plan(d[0], d[1], d[2], d[3])
+    assert info[0] == 1 and info[8] == 1, info          # pyramid-region kernels cover the call
+    out = MSDA.ms_deform_attn_forward(*d, 64)
+    torch.testing.assert_close(out.cpu(), O.msda_forward(value, shapes, lsi, loc, attn), rtol=1e-4, atol=1e-6)
+    gd = go.to(dev)
+    grads = MSDA.ms_deform_attn_backward(*d, gd, 64)
+    want = O.msda_backward(value, shapes, lsi, loc, attn, go)
+    torch.testing.assert_close(grads[0].cpu(), want[0], rtol=1e-3, atol=1e-5 * float(want[0].abs().max()))
+    torch.testing.assert_close(grads[2].cpu(), want[2], rtol=1e-3, atol=1e-5)
+    for _ in range(3):
+        MSDA.ms_deform_attn_backward(*d, gd, 64)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        MSDA.ms_deform_attn_backward(*d, gd, 64)
+    b.record()
+    b.synchronize()
+    assert a.elapsed_time(b) / 5 < 2.5, a.elapsed_time(b) / 5
+    # a decoder-shaped call (Lq != S) through the same two functions
+    value2, shapes2, lsi2, loc2, attn2 = O.random_inputs(N, 300, Mh, 32, shapes_l, P, seed=9)
+    d2 = [t.to(dev) for t in (value2, shapes2, lsi2, loc2, attn2)]
+    assert MSDA.pyramid_plan(d2[0], d2[1], d2[2], d2[3])[0] == 0
+    torch.testing.assert_close(MSDA.ms_deform_attn_forward(*d2, 64).cpu(),
+                               O.msda_forward(value2, shapes2, lsi2, loc2, attn2), rtol=1e-4, atol=1e-6)
