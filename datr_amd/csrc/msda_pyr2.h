@@ -195,6 +195,10 @@ inline bool build_pyr2_meta(Pyr2Meta &pm, const int64_t *sh, const int64_t *ls, 
             double c;
             if (!p2_try_grid(trial, env, M, ry, rx, &c)) continue;
             c *= 1.0 + 4.0 * (trial.nph - 1) + (trial.tpw < 2 ? 0.5 : 0.0) + (trial.tpw > 2 ? 0.25 : 0.0);
+            // among the single-phase, two-tasks-per-wave grids the FINEST wins (shortest tail; in the
+            // training step: 12x16 175 us, 10x16 178, 7x14 180 at 1333x800)
+            if (trial.nph == 1 && trial.tpw == 2)
+                c = 1e6 / (double)(ry * rx) * (1.0 + 0.02 * std::fabs(std::log(((double)pm.H[0] / ry) / ((double)pm.W[0] / rx))));
             if (c < best) { best = c; by = ry; bx = rx; }
         }
     if (!by) return false;
