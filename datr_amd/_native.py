@@ -71,6 +71,8 @@ _SIGNATURES = {
     "datr_wino_weights_f32": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
     "datr_conv3x3_wino_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, _vp],
+    "datr_conv3x3_cout1_forward_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "datr_conv3x3_cout1_backward_f32": [_vp, _i64, _i64, _i64, _vp, ctypes.c_float, _vp, _vp, _vp, _vp],
     "datr_focal_loss_forward_f32": [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
                                     _vp, _vp, _vp],
     "datr_focal_loss_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float,
@@ -81,6 +83,11 @@ _SIGNATURES = {
 class WinoLevel(ctypes.Structure):
     """`datr_wino_level` of include/datr_hip.h."""
     _fields_ = [("x", _vp), ("y", _vp), ("gate", _vp), ("H", _i64), ("W", _i64)]
+
+
+class C1Level(ctypes.Structure):
+    """`datr_c1_level` of include/datr_hip.h."""
+    _fields_ = [("x", _vp), ("y", _vp), ("dx", _vp), ("H", _i64), ("W", _i64)]
 
 
 class WinoWgradLevel(ctypes.Structure):
@@ -114,6 +121,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_groupnorm_partial_floats.argtypes = [_i64, _i64, _i64, _i64]
     lib.datr_wino_wgrad_partial_floats.restype = ctypes.c_int64
     lib.datr_wino_wgrad_partial_floats.argtypes = [_vp, _i64, _i64, _i64, _i64]
+    lib.datr_conv3x3_cout1_partial_floats.restype = ctypes.c_int64
+    lib.datr_conv3x3_cout1_partial_floats.argtypes = [_vp, _i64, _i64]
     lib.datr_ema_piece_elements.restype = ctypes.c_int64
     lib.datr_ema_piece_elements.argtypes = []
     lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64

@@ -18,10 +18,58 @@ from torch.autograd.function import once_differentiable
 
 from .wino import _nhwc, wino_conv3x3, wino_filter, wino_wgrad
 
+
+def _c1_levels(xs, ys, dxs=None):
+    from . import _native
+    levels = (_native.C1Level * len(xs))()
+    for i, x in enumerate(xs):
+        levels[i] = _native.C1Level(x.data_ptr(), ys[i].data_ptr(), 0 if dxs is None else dxs[i].data_ptr(),
+                                    x.shape[2], x.shape[3])
+    return levels
+
+
+def classifier_forward(acts, weight, bias):
+    """[conv2d(a, weight, bias, padding=1) for a in acts] for a one-output-channel 3x3 filter on
+    channels_last levels [N, C, H, W] (csrc/conv_cout1.hip: a stream over the activations, all
+    levels per call).  -> list of [N, 1, H, W]."""
+    import ctypes
+    from . import _native
+    n = acts[0].shape[0]
+    outs = [torch.empty((n, 1, a.shape[2], a.shape[3]), dtype=a.dtype, device=a.device) for a in acts]
+    w = weight.contiguous()
+    with torch.cuda.device(acts[0].device):
+        levels = _c1_levels(acts, outs)
+        rc = _native.lib.datr_conv3x3_cout1_forward_f32(ctypes.addressof(levels), len(acts), n, acts[0].shape[1],
+                                                        w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                        _native.current_stream_ptr(acts[0].device))
+    _native.check(rc, "conv3x3_cout1_forward")
+    return outs
+
+
+def classifier_backward(acts, douts, weight, slope):
+    """-> (dz per level = LeakyReLU-gated data gradient, channels_last; dW [1, C, 3, 3]; db [1])."""
+    import ctypes
+    from . import _native
+    n = acts[0].shape[0]
+    douts = [d.contiguous() for d in douts]
+    dzs = [torch.empty_like(a) for a in acts]                     # channels_last like the activations
+    w = weight.contiguous()
+    dw, db = torch.empty_like(w), torch.empty(1, dtype=w.dtype, device=w.device)
+    levels = _c1_levels(acts, douts, dzs)
+    floats = int(_native.lib.datr_conv3x3_cout1_partial_floats(ctypes.addressof(levels), len(acts), n))
+    partial = torch.empty(max(floats, 1), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _native.lib.datr_conv3x3_cout1_backward_f32(ctypes.addressof(levels), len(acts), n, acts[0].shape[1], w.data_ptr(),
+                                                         ctypes.c_float(slope), dw.data_ptr(), db.data_ptr(),
+                                                         partial.data_ptr(), _native.current_stream_ptr(w.device))
+    _native.check(rc, "conv3x3_cout1_backward")
+    return dzs, dw, db
+
 # own Winograd-on-MFMA path for the discriminator's 3x3 convolutions (csrc/wino.hip); 0 = the
 # library convolutions under autograd (A/B measurements)
 OWN_D_IMG = os.environ.get("DATR_OWN_D_IMG", "1") != "0"
 OWN_D_IMG_WGRAD = os.environ.get("DATR_OWN_D_IMG_WGRAD", "1") != "0"     # weight gradients in the Winograd domain too
+OWN_CLASSIFIER = os.environ.get("DATR_OWN_CLASSIFIER", "1") != "0"        # the 128 -> 1 classifier (csrc/conv_cout1.hip)
 
 
 def decompose_features(srcs, masks, poss):
@@ -53,8 +101,8 @@ class _DImgPyramid(torch.autograd.Function):
     same kernel on the transposed filter with the previous layer's LeakyReLU gate -- and, for the first
     layer, the reversal's minus sign -- in its epilogue; the weight gradient of a layer is one launch
     of csrc/wino_wgrad.hip over all levels (the same Winograd domain: sum over tiles of
-    (A dY A^T) o (B^T x B), folded by G^T . G), the bias gradient a column sum.  Only the 128 -> 1
-    classifier stays on the library."""
+    (A dY A^T) o (B^T x B), folded by G^T . G), the bias gradient a column sum.  The 128 -> 1 classifier
+    is a streaming kernel of its own (csrc/conv_cout1.hip), forward and backward."""
 
     SLOPE = 0.2
 
@@ -64,7 +112,8 @@ class _DImgPyramid(torch.autograd.Function):
         a1 = wino_conv3x3(xs, wino_filter(w1), w1.shape[0], shift=b1, slope=_DImgPyramid.SLOPE)
         a2 = wino_conv3x3(a1, wino_filter(w2), w2.shape[0], shift=b2, slope=_DImgPyramid.SLOPE)
         a3 = wino_conv3x3(a2, wino_filter(w3), w3.shape[0], shift=b3, slope=_DImgPyramid.SLOPE)
-        outs = [F.conv2d(a, wc, bc, padding=1) for a in a3]
+        ctx.own_classifier = OWN_CLASSIFIER and wc.shape[:2] == (1, 128) and all(a.shape[1] == 128 for a in a3)
+        outs = classifier_forward(a3, wc, bc) if ctx.own_classifier else [F.conv2d(a, wc, bc, padding=1) for a in a3]
         ctx.save_for_backward(w1, w2, w3, wc, *xs, *a1, *a2, *a3)
         ctx.levels = len(xs)
         return tuple(outs)
@@ -98,9 +147,12 @@ class _DImgPyramid(torch.autograd.Function):
                     dw = gw if dw is None else dw.add_(gw)
             return dw, db
 
-        # classifier (128 -> 1): library kernels; its data gradient is gated by hand
+        # classifier (128 -> 1): own streaming kernels (csrc/conv_cout1.hip), the LeakyReLU gate of
+        # conv3 applied in the data gradient; DATR_OWN_CLASSIFIER=0: library kernels, gated by hand
         dz3, dwc, dbc = [], None, None
-        for do, a in zip(douts, a3):
+        if ctx.own_classifier:
+            dz3, dwc, dbc = classifier_backward(a3, douts, wc, slope)
+        for do, a in (() if ctx.own_classifier else zip(douts, a3)):
             da, gw, gb = conv_bwd(do.contiguous(), a, wc, [1], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                   [True, True, True])
             dz3.append(_nhwc(torch.where(a > 0, da, da * slope)))

@@ -236,6 +236,25 @@ int datr_conv3x3_wino_nhwc_f32(const datr_wino_level *levels, int64_t nlevels, i
                                int64_t Cout, const float *u, const float *scale, const float *shift,
                                float slope, float gate_slope, float out_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution with ONE output channel, NHWC fp32 (csrc/conv_cout1.hip): the
+ * classifier of the image-level discriminator (/root/reference/models/dino/DA_utils.py:67,78), all
+ * pyramid levels of a call (they share the filter).  w: the torch weight [1, C, 3, 3] contiguous;
+ * C == 128.  forward: y[N, H, W] = bias + conv(x[N, H, W, C], w).
+ * backward, per level: x = the classifier's INPUT a = lrelu(z) (DA_utils.py:76), y = dY[N, H, W],
+ *   dx[N, H, W, C] = gate(a) * conv_transpose(dY, w), gate = 1 where a > 0 else `slope` -- i.e. the
+ *   gradient w.r.t. the pre-activation z, what the next data-gradient launch consumes;
+ *   dw[1, C, 3, 3] and db[1] (may be NULL) are OVERWRITTEN with the sums over all levels, added in a
+ *   fixed order (bitwise reproducible).  `partial`: datr_conv3x3_cout1_partial_floats(...) floats.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { const float *x; float *y; float *dx; int64_t H, W; } datr_c1_level;
+int64_t datr_conv3x3_cout1_partial_floats(const datr_c1_level *levels, int64_t nlevels, int64_t N);
+int datr_conv3x3_cout1_forward_f32(const datr_c1_level *levels, int64_t nlevels, int64_t N, int64_t C,
+                                   const float *w, const float *bias, void *stream);
+int datr_conv3x3_cout1_backward_f32(const datr_c1_level *levels, int64_t nlevels, int64_t N, int64_t C,
+                                    const float *w, float slope, float *dw, float *db, float *partial,
+                                    void *stream);
+
 /* Weight gradient of the same convolutions in the Winograd domain (csrc/wino_wgrad.hip):
  * dW = G^T [ sum over 2x2 tiles (A dY A^T) o (B^T x B) ] G, summed over all levels (they share the
  * filter) -- replaces `torch.ops.aten.convolution_backward(dz, x, w, ..., [False, True, False])`, i.e.

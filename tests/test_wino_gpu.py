@@ -294,3 +294,37 @@ def test_wino_wgrad_full_size_pyramid_against_the_library():
     assert float((got - lib).abs().max()) <= 2e-5 * scale
     mix = wino_wgrad(xs, [0.5 * a + b for a, b in zip(d1, d2)], w)
     assert float((mix - (0.5 * got + wino_wgrad(xs, d2, w))).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("sizes", [[(100, 167), (50, 84), (25, 42), (13, 21)], [(1, 1), (2, 3), (7, 5)], [(33, 17)]])
+def test_one_channel_classifier_matches_float64_autograd(sizes):
+    """csrc/conv_cout1.hip -- the discriminator's 128 -> 1 classifier (DA_utils.py:67,78) on all pyramid
+    levels: forward, the LeakyReLU-gated data gradient, weight and bias gradient summed over the
+    levels, against F.conv2d under autograd in float64; 1x1 / ragged maps exercise the zero padding;
+    two runs are bitwise equal (fixed-order reduction)."""
+    from datr_amd.domain import classifier_backward, classifier_forward
+    dev = torch.device("cuda:0")
+    torch.manual_seed(len(sizes))
+    N, C, slope = 2, 128, 0.2
+    w = torch.randn(1, C, 3, 3, device=dev) / (3 * C ** 0.5)
+    b = torch.randn(1, device=dev)
+    zs = [torch.randn(N, C, h, ww, device=dev) for h, ww in sizes]            # conv3's pre-activations
+    acts = [_cl(F.leaky_relu(z, slope)) for z in zs]
+    outs = classifier_forward(acts, w, b)
+    douts = [torch.randn(N, 1, h, ww, device=dev) for h, ww in sizes]
+    dzs, dw, db = classifier_backward(acts, douts, w, slope)
+    dzs2, dw2, db2 = classifier_backward(acts, douts, w, slope)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and all(torch.equal(a, b_) for a, b_ in zip(dzs, dzs2))
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    zd = [z.double().requires_grad_(True) for z in zs]
+    ref = [F.conv2d(F.leaky_relu(z, slope), wd, bd, padding=1) for z in zd]
+    grads = torch.autograd.grad(ref, [wd, bd] + zd, [d.double() for d in douts])
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape
+        torch.testing.assert_close(o.double(), r.detach(), rtol=1e-5, atol=1e-5)
+    scale = float(grads[0].abs().max())
+    torch.testing.assert_close(dw.double(), grads[0], rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(db.double(), grads[1], rtol=1e-4, atol=1e-5 * float(grads[1].abs().max()))
+    for dz, g in zip(dzs, grads[2:]):
+        assert dz.is_contiguous(memory_format=torch.channels_last) or dz.shape[2] * dz.shape[3] == 1
+        torch.testing.assert_close(dz.double(), g, rtol=1e-5, atol=1e-6)
