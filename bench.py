@@ -56,6 +56,7 @@ class MsdaTimer:
         self.orig = msda.ms_deform_attn_forward
         self.events = []
         self.shape = None
+        self.phased = None
         self.enabled = False
 
     def install(self):
@@ -68,6 +69,10 @@ class MsdaTimer:
                 self.events.append((a, b))
                 self.shape = (value.shape[0], value.shape[1], value.shape[2], value.shape[3],
                               loc.shape[3] * loc.shape[4], loc.shape[1])
+                if self.phased is None:
+                    env = kw.get("envelope")
+                    self.phased = bool(kw.get("route", 0) == 0 and self.msda.pyramid_plan(
+                        shapes, lsi, value.shape[0], value.shape[2], value.shape[3], loc.shape[4], env)["phased"])
                 return out
             return self.orig(value, shapes, lsi, loc, attn, step, **kw)
         self.msda.ms_deform_attn_forward = timed
@@ -92,12 +97,15 @@ class MsdaTimer:
             rec = json.load(open(pmc))
             sh = rec["shape"]
             if (sh["N"], sh["S"], sh["M"], sh["D"], sh["Lq"]) == (N, S, M, D, Lq) and sh["L"] * sh["P"] == K \
-                    and self.msda.PYR_FORWARD:
+                    and self.msda.PYR_FORWARD and rec.get("kernel") and \
+                    (("pyr2" in rec["kernel"]) == bool(self.phased)):
                 fetch, write = rec["FETCH_SIZE_KB_per_launch"], rec["WRITE_SIZE_KB_per_launch"]
                 traffic = int(round((2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024))
                 traffic_src = f"profiles/{PMC_RECORD}: (2 x mean FETCH_SIZE + mean WRITE_SIZE) x 1024, " \
                               f"{len(fetch)} + {len(write)} launches"
-        if self.msda.PYR_FORWARD and D == 32 and K == 16:
+        if self.msda.PYR_FORWARD and D == 32 and K == 16 and self.phased:
+            kernel = "msda_fwd_pyr2_d32 (encoder call, csrc/msda_fwd_pyr2.hip: all levels out of LDS windows)"
+        elif self.msda.PYR_FORWARD and D == 32 and K == 16:
             kernel = "msda_fwd_pyr_d32 (encoder call, csrc/msda_fwd_pyr.hip)"
         else:
             kernel = "msda_fwd_rows<8,16> (encoder call)"
@@ -106,6 +114,42 @@ class MsdaTimer:
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "kernel": kernel, "launches": len(us),
                 "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
+
+
+def msda_rand_roofline(device, shape):
+    """SURVEY.md 8d's micro-bench inputs for the same launch shape: value = rand * 0.01, loc ~ U[0, 1)
+    over the whole image, attn = softmax(randn) -- the reference op test's recipe
+    (/root/reference/models/dino/ops/test.py:28-37), the worst case for locality: no window plan helps,
+    the call runs whatever kernel the library picks for it.  HIP events, mean of 10 launches."""
+    from datr_amd import msda
+    N, S, M, D, K, Lq = shape
+    if (N, M, D, K, Lq) != (N, 8, 32, 16, S):
+        return None
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = torch.tensor([(100, 167), (50, 84), (25, 42), (13, 21)], dtype=torch.int64)
+    if int(shapes.prod(1).sum()) != S:
+        return None
+    lsi = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    value = (torch.rand(N, S, M, D, generator=g) * 0.01).to(device)
+    loc = torch.rand(N, Lq, M, 4, 4, 2, generator=g).to(device)
+    attn = torch.softmax(torch.randn(N, Lq, M, 16, generator=g), -1).view(N, Lq, M, 4, 4).to(device)
+    shapes, lsi = shapes.to(device), lsi.to(device)
+    f = lambda: msda.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64, route=1)
+    for _ in range(3):
+        f()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        f()
+    b.record()
+    b.synchronize()
+    us = a.elapsed_time(b) * 1e3 / 10
+    algo = 4 * N * (S * M * D + Lq * M * K * 3 + Lq * M * D)
+    return {"bound": "hbm", "achieved": round(algo / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(algo / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": "msda_fwd_rows<8,16> (row kernel, corner rows through the vector-memory path)",
+            "inputs": "loc ~ U[0,1) over the image (ops/test.py recipe), stand-alone launches after the timed region",
+            "mean_us": round(us, 2), "algorithmic_bytes": algo}
 
 
 def teacher_student_stage(args, device):
@@ -433,7 +477,16 @@ def main():
             "roofline": roof,
         }
         if timer.shape is not None:
+            line["roofline_rand_locations"] = msda_rand_roofline(device, timer.shape)
             line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
+            # the whole step's matrix-pipe utilisation from the committed PMC pass (every launch of
+            # five steps), beside the isolated figure above
+            mf = os.path.join(ROOT, "profiles", "r03_step_mfma.txt")
+            if os.path.exists(mf):
+                for ln in open(mf):
+                    if ln.startswith("all kernels of the run"):
+                        line["mfma"]["in_step_matrix_pipe_busy"] = float(ln.split()[-1].rstrip("%")) / 100.0
+                        line["mfma"]["in_step_source"] = "profiles/r03_step_mfma.txt (PMC SQ_VALU_MFMA_BUSY_CYCLES, tools/pmc_step_mfma.sh)"
         if world == 1 and not args.no_cpu_baseline and not source_only:
             if dist.is_initialized():       # one-rank RCCL mode: the CPU leg must not see a NCCL group
                 dist.destroy_process_group()

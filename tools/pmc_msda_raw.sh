@@ -1,0 +1,50 @@
+#!/bin/bash
+# HBM traffic of the encoder MSDA kernels as RAW per-launch rows (rocprofv3 PMC, one counter per
+# pass with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).
+# Writes <out>.json with the FETCH_SIZE / WRITE_SIZE value (KB) of every launch of the N = 4 encoder
+# forward (the kernel bench.py's roofline names) and backward; bench.py applies
+#   bytes = (2 x mean FETCH_SIZE + mean WRITE_SIZE) x 1024
+# itself (gfx950 tallies 128-B requests of 16 B/lane reads at 64 B: FETCH_SIZE x 2; WRITE_SIZE as reported).
+#   usage: tools/pmc_msda_raw.sh profiles/r03_msda_pmc.json      (on the GPU box, from the repo root)
+set -e
+OUT=${1:-gpurun_out/msda_pmc.json}
+REPO=$PWD
+export TMPDIR=/tmp
+mkdir -p "$(dirname "$OUT")" /tmp/pmcraw
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmcraw/$C
+  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcraw/$C -o run -- \
+      python $REPO/tools/bench_msda.py --iters 6 --dist model --n 4 --encoder-only > /tmp/pmcraw/$C.log 2>&1) || true
+done
+python - "$OUT" <<'PY'
+import csv, glob, json, re, sys
+out = {"source": "tools/pmc_msda_raw.sh: rocprofv3 --pmc <counter> --kernel-trace, one counter per pass; "
+                 "tools/bench_msda.py --dist model --n 4 --encoder-only (measured envelope)",
+       "shape": {"N": 4, "S": 22223, "M": 8, "D": 32, "L": 4, "P": 4, "Lq": 22223},
+       "unit": "KB as rocprofv3 reports FETCH_SIZE / WRITE_SIZE",
+       "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests of 16 B/lane reads at 64 B); "
+                     "WRITE_SIZE as reported; applied by the reader, the rows here are raw"}
+kern = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"/tmp/pmcraw/{c}/**/*counter_collection.csv", recursive=True)
+    rows = list(csv.DictReader(open(f[0]))) if f else []
+    for r in rows:
+        if r.get("Counter_Name") != c:
+            continue
+        k = r["Kernel_Name"]
+        for tag, pat in (("forward", "msda_fwd_pyr"), ("backward", "msda_bwd_pyr")):
+            if pat in k:
+                kern.setdefault(tag, {"kernel": (re.search(r"msda_\w+(<\d+>)?", k) or [k])[0]}).setdefault(c + "_KB_per_launch", []).append(float(r["Counter_Value"]))
+fw = kern.get("forward", {})
+out["kernel"] = fw.get("kernel")
+out["FETCH_SIZE_KB_per_launch"] = fw.get("FETCH_SIZE_KB_per_launch", [])
+out["WRITE_SIZE_KB_per_launch"] = fw.get("WRITE_SIZE_KB_per_launch", [])
+out["backward"] = kern.get("backward", {})
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+for tag in ("forward", "backward"):
+    k = kern.get(tag, {})
+    f_, w_ = k.get("FETCH_SIZE_KB_per_launch", []), k.get("WRITE_SIZE_KB_per_launch", [])
+    if f_ and w_:
+        print(tag, k.get("kernel"), "launches", len(f_), len(w_), "mean FETCH KB %.0f WRITE KB %.0f -> traffic %.1f MB" % (
+            sum(f_) / len(f_), sum(w_) / len(w_), (2 * sum(f_) / len(f_) + sum(w_) / len(w_)) * 1024 / 1e6))
+PY
