@@ -657,21 +657,17 @@ int datr_msda_forward_pyramid_f32(const float *value, const int64_t *shapes,
     if (!dims_ok(N, S, M, D, L, Lq, P)) return DATR_EINVAL;
     if (N == 0 || Lq == 0) return DATR_OK;
     if (!value || !shapes || !level_start || !loc || !attn || !out) return DATR_EINVAL;
-    // The phased all-LDS kernel wins when its windows are small enough for ONE phase -- which takes a
-    // measured envelope (one-directional heads); with the symmetric default or wide envelopes
-    // round 2's kernel (level 0 through the vector-memory path) is ahead (profiles/r03_msda_fwd.md).
-    // DATR_MSDA_PYR2=0 never, =2 whenever the plan exists (A/B measurements).
+    // The phased all-LDS kernel (msda_fwd_pyr2.hip) whenever a window plan exists -- with or without
+    // an envelope it is ahead of round 2's kernel (N = 4 call at 1333x800: 111 vs 168 us with the
+    // measured envelope of the ring initialisation, 135 vs 168 with the symmetric default, 136 vs 180 /
+    // 210 vs 222 for offsets ~ N(0, 1.5 / 2.5 px); profiles/r03_msda_fwd.md).  No plan (envelopes too
+    // wide for the LDS): round 2's kernel / the row kernel.  DATR_MSDA_PYR2=0: never (A/B runs).
     static const int pyr2 = getenv("DATR_MSDA_PYR2") ? atoi(getenv("DATR_MSDA_PYR2")) : 1;
     // 32-bit sample offsets inside the kernel: N * Lq * M * 16 samples * 8 B
-    if (pyr2 && (envelope_host || pyr2 == 2) && shapes_host && level_start_host && M <= 8 &&
-        N * Lq * M * 128 < ((int64_t)1 << 31)) {
-        int32_t info[8];
-        if (datr_internal_msda_fwd_pyr2_plan(shapes_host, level_start_host, S, M, envelope_host, nullptr, info) == DATR_OK &&
-            (info[3] == 1 || pyr2 == 2)) {
-            const int rc = datr_internal_msda_fwd_pyr2_d32(value, loc, attn, shapes_host, level_start_host,
-                                                           envelope_host, N, S, M, D, L, Lq, P, out, stream);
-            if (rc != DATR_EUNSUPPORTED) return rc;
-        }
+    if (pyr2 && shapes_host && level_start_host && M <= 8 && N * Lq * M * 128 < ((int64_t)1 << 31)) {
+        const int rc = datr_internal_msda_fwd_pyr2_d32(value, loc, attn, shapes_host, level_start_host,
+                                                       envelope_host, N, S, M, D, L, Lq, P, out, stream);
+        if (rc != DATR_EUNSUPPORTED) return rc;
     }
     return datr_msda_forward_tiled_f32(value, shapes, level_start, shapes_host, level_start_host, loc,
                                        attn, N, S, M, D, L, Lq, P, out, stream);
@@ -688,7 +684,7 @@ int datr_msda_pyramid_plan(const int64_t *shapes_host, const int64_t *level_star
     (void)datr_internal_msda_bwd_pyr_plan(shapes_host, level_start_host, S, M, info + 8);
     // [11]: does datr_msda_forward_pyramid_f32 take the phased kernel for this envelope?
     static const int pyr2 = getenv("DATR_MSDA_PYR2") ? atoi(getenv("DATR_MSDA_PYR2")) : 1;
-    info[11] = info[0] && pyr2 && ((envelope_host && info[3] == 1) || pyr2 == 2);
+    info[11] = info[0] && pyr2;
     return DATR_OK;
 }
 

@@ -51,6 +51,9 @@
 #ifndef PYR2_ABLATE
 #define PYR2_ABLATE 0
 #endif
+#ifndef PYR2_BANDS
+#define PYR2_BANDS 1
+#endif
 #ifndef PYR2_LDS_DEPTH
 #define PYR2_LDS_DEPTH 1          // samples whose corner rows are in flight out of LDS
 #endif
@@ -231,10 +234,22 @@ __global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void ms
     {
     const int item = blockIdx.x;      // one (image, region, head) item per workgroup, head fastest:
                                       // workgroup b runs on XCD b % 8, an XCD's L2 holds one head's slice
+#if PYR2_BANDS
+    // XCD = item % 8 owns a BAND of regions with all heads (dense lines in its L2) instead of one head
+    // everywhere (every 8th 128-B line): item = ((j * M + m) * 8 + band) within an image
+    const int per_band = (nreg + 7) / 8;
+    const int n = item / (8 * per_band * M);
+    const int rem = item - n * (8 * per_band * M);
+    const int band = rem % 8, m = (rem / 8) % M, jj = rem / (8 * M);
+    const int reg = band * per_band + jj;
+    if (reg >= nreg) return;
+    const int ry = reg / pm.nRx, rx = reg % pm.nRx;
+#else
     const int m = item % M;
     const int reg = (item / M) % nreg;
     const int n = item / (M * nreg);
     const int ry = reg / pm.nRx, rx = reg % pm.nRx;
+#endif
 
     const float *base = value + ((size_t)n * S * M + m) * 32;
     const int records = (S * M - m) * kRowBytes;                   // bytes from `base` to the end of item n
@@ -312,9 +327,12 @@ __global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void ms
                   ((float)(lv[l].wy0 + lv[l].WH / 2) + 0.5f) / (float)lv[l].H};
         r.a = 0.0625f;
 #else
-        const auto v = __builtin_amdgcn_raw_buffer_load_b64(loc_rsrc, (so + 4 * l + j) * 8, 0, 2);
+        // default cache policy, NOT nt: the four levels' pieces of a query's 128-B location line are
+        // read at four different times; with the non-temporal hint every one of them went back to
+        // HBM (FETCH_SIZE 283 -> 147 MB per launch, 155 -> 133 us without it)
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(loc_rsrc, (so + 4 * l + j) * 8, 0, 0);
         r.xy = __builtin_bit_cast(f2, v);
-        r.a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(attn_rsrc, (so + 4 * l + j) * 4, 0, 2));
+        r.a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(attn_rsrc, (so + 4 * l + j) * 4, 0, 0));
 #endif
         return r;
     };
@@ -476,7 +494,11 @@ int launch(const float *value, const float *loc, const float *attn, const Pyr2Me
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     kP2LdsBytes) == hipSuccess;
     if (!attr_ok) return DATR_EUNSUPPORTED;
+#if PYR2_BANDS
+    const long blocks = (long)N * ((pm.nRy * pm.nRx + 7) / 8) * 8 * M;
+#else
     const long blocks = (long)N * pm.nRy * pm.nRx * M;
+#endif
     if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
     hipLaunchKernelGGL(msda_fwd_pyr2_d32<kTPW>, dim3((unsigned)blocks), dim3(kP2Threads),
                        (size_t)kP2WindowRows * kRowBytes, stream, value, loc, attn, pm, (int)S,

@@ -158,7 +158,7 @@ inline bool p2_try_grid(Pyr2Meta &pm, const Pyr2Envelope &env, int M, int nRy, i
     if (cost) {
         // fill bytes of all regions of one image plus a fixed charge per workgroup (prologue)
         const double wgs = (double)nRy * nRx * M;
-        *cost = fill * nRy * nRx + wgs * 8192.0;
+        *cost = fill * nRy * nRx + wgs * 2048.0;
     }
     return true;
 }
@@ -182,11 +182,10 @@ inline bool build_pyr2_meta(Pyr2Meta &pm, const int64_t *sh, const int64_t *ls, 
     if (force && std::sscanf(force, "%dx%d", &fy, &fx) == 2 && fy >= 1 && fx >= 1 && fy <= kP2MaxR && fx <= kP2MaxR) {
         return p2_try_grid(pm, env, M, fy, fx, nullptr);
     }
-    // Measured on the N = 4 call at 1333x800 (profiles/r03_msda_fwd.md): many small single-phase
-    // workgroups beat few large multi-phase ones although they stage more window bytes -- the tail
-    // of a launch is one workgroup's duration and every extra phase costs two barriers plus an
-    // exposed fill.  So: fewest phases first, then at least two tasks per wave if possible (with one
-    // the waves idle through the fills), then the least fill traffic.
+    // Measured on the N = 4 call at 1333x800 (profiles/r03_msda_fwd.md, after the location loads lost
+    // their non-temporal hint): 8x12 111 us, 7x14 114, 5x12 (two phases) 117, 10x16 127, 12x16 133,
+    // 16x16 148 -- the least staged bytes win, an extra phase costs about 15 %, one task per wave
+    // leaves the waves idle through the fills.
     double best = 1e300;
     int by = 0, bx = 0;
     Pyr2Meta trial = pm;
@@ -194,11 +193,7 @@ inline bool build_pyr2_meta(Pyr2Meta &pm, const int64_t *sh, const int64_t *ls, 
         for (int rx = 1; rx <= kP2MaxR; ++rx) {
             double c;
             if (!p2_try_grid(trial, env, M, ry, rx, &c)) continue;
-            c *= 1.0 + 4.0 * (trial.nph - 1) + (trial.tpw < 2 ? 0.5 : 0.0) + (trial.tpw > 2 ? 0.25 : 0.0);
-            // among the single-phase, two-tasks-per-wave grids the FINEST wins (shortest tail; in the
-            // training step: 12x16 175 us, 10x16 178, 7x14 180 at 1333x800)
-            if (trial.nph == 1 && trial.tpw == 2)
-                c = 1e6 / (double)(ry * rx) * (1.0 + 0.02 * std::fabs(std::log(((double)pm.H[0] / ry) / ((double)pm.W[0] / rx))));
+            c *= 1.0 + 0.3 * (trial.nph - 1) + (trial.tpw < 2 ? 0.3 : 0.0);
             if (c < best) { best = c; by = ry; bx = rx; }
         }
     if (!by) return false;

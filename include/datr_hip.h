@@ -112,8 +112,7 @@ int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value
  * windows of footprint + envelope per level in LDS and gathers ALL four levels from there; a
  * sample outside the envelope is fetched from global memory instead, so the envelope is a
  * performance hint only -- results never depend on it.  NULL = symmetric +-4.5 px (the reach of the
- * module's initial offset ring -- with which, as with any envelope too wide for all four windows to
- * fit one LDS phase, the call runs round 2's kernel: datr_msda_forward_tiled_f32).  Shapes the phased kernel does not cover (D != 32, L != 4, P != 4,
+ * module's initial offset ring).  Envelopes too wide for any window plan, and shapes the phased kernel does not cover (D != 32, L != 4, P != 4,
  * Lq != S, M > 8) fall through to datr_msda_forward_tiled_f32. */
 int datr_msda_forward_pyramid_f32(const float *value, const int64_t *shapes,
                                   const int64_t *level_start, const int64_t *shapes_host,
@@ -125,7 +124,7 @@ int datr_msda_forward_pyramid_f32(const float *value, const int64_t *shapes,
  * [3] phases, [4] 16-query tasks per wave, [5] workgroups per image, [6] LDS fill KiB per workgroup
  * (head 0), [7] largest phase in 128-B rows (head 0); [8] backward covered by the pyramid-region
  * kernel, [9] nRy, [10] nRx; [11] datr_msda_forward_pyramid_f32 would run the phased kernel (it does
- * when an envelope is given and all four windows fit one phase; otherwise round 2's kernel); rest 0. */
+ * whenever [0] is set); rest 0. */
 int datr_msda_pyramid_plan(const int64_t *shapes_host, const int64_t *level_start_host, int64_t N,
                            int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
                            const float *envelope_host, int32_t *info);
