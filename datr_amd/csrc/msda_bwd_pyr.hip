@@ -59,6 +59,9 @@ extern "C" void datr_probe_pyr_bwd_phase_cycles(unsigned long long *out, int res
 
 namespace {
 
+#ifndef PYRB_BANDS
+#define PYRB_BANDS 0
+#endif
 #ifndef PYRB_THREADS
 #define PYRB_THREADS 512
 #endif
@@ -137,10 +140,22 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
     const int bid = blockIdx.x;
+#if PYRB_BANDS
+    // XCD = bid % 8 owns a BAND of regions with all heads (dense lines in its L2; a grad_value line is
+    // touched by one XCD's workgroups only, close together in time): bid = ((j * M + m) * 8 + band)
+    const int nreg_ = pm.nRy * pm.nRx, per_band = (nreg_ + 7) / 8;
+    const int n = bid / (8 * per_band * M);
+    const int rem_ = bid - n * (8 * per_band * M);
+    const int band = rem_ % 8, m = (rem_ / 8) % M, jj = rem_ / (8 * M);
+    const int reg = band * per_band + jj;
+    if (reg >= nreg_) return;
+    const int ry = reg / pm.nRx, rx = reg % pm.nRx;
+#else
     const int m = bid % M;
     const int reg = (bid / M) % (pm.nRy * pm.nRx);
     const int n = bid / (M * pm.nRy * pm.nRx);
     const int ry = reg / pm.nRx, rx = reg % pm.nRx;
+#endif
     const unsigned row_stride = (unsigned)M * kRowBytes;
     const size_t Lq = (size_t)S;
 
@@ -446,7 +461,11 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     kLdsBytes) == hipSuccess;
     if (!attr_ok) return DATR_EUNSUPPORTED;
+#if PYRB_BANDS
+    const long blocks = (long)N * ((pm.nRy * pm.nRx + 7) / 8) * 8 * M;
+#else
     const long blocks = (long)N * pm.nRy * pm.nRx * M;
+#endif
     if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
     hipLaunchKernelGGL(msda_bwd_pyr_d32, dim3((unsigned)blocks), dim3(kThreads), (size_t)kLdsBytes,
                        (hipStream_t)stream, grad_out, value, loc, attn, pm, (int)S, (int)M, grad_value,
