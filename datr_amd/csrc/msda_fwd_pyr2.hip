@@ -51,6 +51,9 @@
 #ifndef PYR2_ABLATE
 #define PYR2_ABLATE 0
 #endif
+#ifndef PYR2_OUT_NT
+#define PYR2_OUT_NT 1
+#endif
 #ifndef PYR2_BANDS
 #define PYR2_BANDS 1
 #endif
@@ -464,8 +467,13 @@ __global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void ms
         const bool live = ti * 16 + slot < nq;
         if (live && (!(PYR2_ABLATE & 16) || accA[t].x == 123.456f)) {
             float *dst = out + (size_t)soff[t] * 2;                // 16 samples <-> 32 output floats
+#if PYR2_OUT_NT
             __builtin_nontemporal_store(accA[t], reinterpret_cast<f4 *>(dst + (chan >> 2)));
             __builtin_nontemporal_store(accB[t], reinterpret_cast<f4 *>(dst + ((chan ^ 64) >> 2)));
+#else
+            *reinterpret_cast<f4 *>(dst + (chan >> 2)) = accA[t];
+            *reinterpret_cast<f4 *>(dst + ((chan ^ 64) >> 2)) = accB[t];
+#endif
         }
     }
     }

@@ -18,6 +18,10 @@
 
 #include "datr_hip.h"
 
+#ifndef DATR_PROLOGUE_NT
+#define DATR_PROLOGUE_NT 1
+#endif
+
 namespace {
 
 constexpr int kM = 8, kL = 4, kP = 4;            // heads, levels, points: the DINO configuration
@@ -71,9 +75,15 @@ __global__ __launch_bounds__(256) void prologue_fwd(const float *__restrict__ bo
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 v0 = {a0.x, a0.y, a0.z, a0.w}, v1 = {a1.x, a1.y, a1.z, a1.w};
         const f4 v2 = {e.x * inv, e.y * inv, e.z * inv, e.w * inv};
+#if DATR_PROLOGUE_NT
         __builtin_nontemporal_store(v0, reinterpret_cast<f4 *>(loc + i * 8));
         __builtin_nontemporal_store(v1, reinterpret_cast<f4 *>(loc + i * 8 + 4));
         __builtin_nontemporal_store(v2, reinterpret_cast<f4 *>(attn + i * 4));
+#else
+        *reinterpret_cast<f4 *>(loc + i * 8) = v0;
+        *reinterpret_cast<f4 *>(loc + i * 8 + 4) = v1;
+        *reinterpret_cast<f4 *>(attn + i * 4) = v2;
+#endif
     }
 }
 
