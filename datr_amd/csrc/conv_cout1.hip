@@ -150,7 +150,7 @@ __global__ void c1_wgrad_fold(const float *__restrict__ partial, int blocks, flo
 
 int blocks_for(long npix) {
     const long want = (npix + kPixPerBlock * 8 - 1) / (kPixPerBlock * 8);       // >= 8 pixels per group
-    return (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    return (int)(want < 1 ? 1 : (want > 256 ? 256 : want));       // the fold walks the partials serially
 }
 
 }  // namespace

@@ -290,6 +290,37 @@ __global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void ms
     const int nph = pm.nph;
     const int4v phm = *reinterpret_cast<const int4v *>(pm.ph_mask);
 
+    // stage the windows of one phase's levels by LDS-DMA: one wave instruction moves 64 x 16 B = 8
+    // window pixels straight into LDS (lane i lands at base + 16 i); an out-of-image pixel gets an
+    // out-of-range offset and reads zeros
+    auto fill_phase = [&](int mask, int l_first) {
+        if (PYR2_ABLATE & 1) return;
+#pragma unroll
+        for (int lf = 0; lf < 4; ++lf) {
+            if (lf < l_first || !((mask >> lf) & 1)) continue;
+            const int WW = lv[lf].WW, cnt = lv[lf].WH * WW * 8;
+            const int wy0 = lv[lf].wy0, wx0 = lv[lf].wx0;
+            const int Hl = lv[lf].H, Wl = lv[lf].W, st = lv[lf].start;
+            const float inv = 1.0f / (float)WW;
+            const int lbase = lv[lf].lbase;
+            for (int i0 = wave * 64; i0 < cnt; i0 += kP2Threads) {
+                const int i = i0 + lane;
+                const int pix = i >> 3, chunk = i & 7;
+                const int wr = (int)(((float)pix + 0.5f) * inv);
+                const int wc = pix - wr * WW;
+                const int y = wy0 + wr, x = wx0 + wc;
+                const bool in = i < cnt && (unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl;
+                const unsigned off = in ? (unsigned)(st + y * Wl + x) * row_stride + (unsigned)chunk * 16u
+                                        : kOutOfRange;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, reinterpret_cast<lds_void *>(lbase + i0 * 16),
+                                                         16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+    // the first phase's windows are requested BEFORE the query decode and the location loads below:
+    // the fill is the longest latency of the prologue
+    fill_phase(phm.x, 0);
+
     // Lane roles.  4 lanes share a query; lane j owns the 16-B pieces j and j + 4 of every row and
     // works out the geometry of POINT j.  Quads whose slot has bit 2 set read the upper half first.
     const int slot = lane >> 2, j = lane & 3;
@@ -361,29 +392,7 @@ __global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void ms
             if (next_phase > 0 && !(PYR2_ABLATE & 128)) __syncthreads();   // everyone is done with the old windows
             TICK(1);                                     // waiting for the workgroup before a re-fill
             ++next_phase;
-            if (!(PYR2_ABLATE & 1)) {
-#pragma unroll
-                for (int lf = l; lf < 4; ++lf) {
-                    if (!((mask >> lf) & 1)) continue;
-                    const int WW = lv[lf].WW, cnt = lv[lf].WH * WW * 8;
-                    const int wy0 = lv[lf].wy0, wx0 = lv[lf].wx0;
-                    const int Hl = lv[lf].H, Wl = lv[lf].W, st = lv[lf].start;
-                    const float inv = 1.0f / (float)WW;
-                    const int lbase = lv[lf].lbase;
-                    for (int i0 = wave * 64; i0 < cnt; i0 += kP2Threads) {
-                        const int i = i0 + lane;
-                        const int pix = i >> 3, chunk = i & 7;
-                        const int wr = (int)(((float)pix + 0.5f) * inv);
-                        const int wc = pix - wr * WW;
-                        const int y = wy0 + wr, x = wx0 + wc;
-                        const bool in = i < cnt && (unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl;
-                        const unsigned off = in ? (unsigned)(st + y * Wl + x) * row_stride + (unsigned)chunk * 16u
-                                                : kOutOfRange;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, reinterpret_cast<lds_void *>(lbase + i0 * 16),
-                                                                 16, (int)off, 0, 0, 0);
-                    }
-                }
-            }
+            if (next_phase > 1) fill_phase(mask, l);       // phase 0 was issued in the prologue
             TICK(2);                                     // fill issue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TICK(3);                                     // own fill pieces (and pending locations) landing
