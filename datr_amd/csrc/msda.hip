@@ -681,7 +681,9 @@ int datr_msda_pyramid_plan(const int64_t *shapes_host, const int64_t *level_star
     if (!dims_ok(N, S, M, D, L, Lq, P) || D != 32 || L != 4 || P != 4 || Lq != S) return DATR_OK;
     if (M <= 8 && N * Lq * M * 128 < ((int64_t)1 << 31))
         (void)datr_internal_msda_fwd_pyr2_plan(shapes_host, level_start_host, S, M, envelope_host, nullptr, info);
+    const int32_t cfg_ = info[12];
     (void)datr_internal_msda_bwd_pyr_plan(shapes_host, level_start_host, S, M, info + 8);
+    info[12] = cfg_;
     // [11]: does datr_msda_forward_pyramid_f32 take the phased kernel for this envelope?
     static const int pyr2 = getenv("DATR_MSDA_PYR2") ? atoi(getenv("DATR_MSDA_PYR2")) : 1;
     info[11] = info[0] && pyr2;

@@ -57,9 +57,7 @@
 #ifndef PYR2_BANDS
 #define PYR2_BANDS 1
 #endif
-#ifndef PYR2_LDS_DEPTH
-#define PYR2_LDS_DEPTH 1          // samples whose corner rows are in flight out of LDS
-#endif
+
 
 #ifdef PYR2_PROBE
 // per-phase cycle counters of lane 0 of every wave (development; tools/probes/pyr2_ablate.sh)
@@ -168,9 +166,10 @@ __device__ __forceinline__ void accumulate(f4 &accA, f4 &accB, const Rows &r, co
 }
 
 // The four points of one level (point p's geometry sits in lane p of the quad).
+template <int kDepth>                 // samples whose corner rows are in flight out of LDS
 __device__ __forceinline__ void lds_level(f4 &accA, f4 &accB, const int base, const float (&w)[4],
                                           const int chan, const int row_bytes) {
-#if PYR2_LDS_DEPTH == 1
+  if constexpr (kDepth == 1) {
     Rows r;
     fetch_lds<0>(r, base, chan, row_bytes);
     accumulate<0>(accA, accB, r, w);
@@ -183,7 +182,7 @@ __device__ __forceinline__ void lds_level(f4 &accA, f4 &accB, const int base, co
     PIN(accA, accB);
     fetch_lds<3>(r, base, chan, row_bytes);
     accumulate<3>(accA, accB, r, w);
-#else
+  } else {
     Rows r0, r1;
     fetch_lds<0>(r0, base, chan, row_bytes);
     fetch_lds<1>(r1, base, chan, row_bytes);
@@ -197,7 +196,7 @@ __device__ __forceinline__ void lds_level(f4 &accA, f4 &accB, const int base, co
     accumulate<2>(accA, accB, r0, w);
     PIN(accA, accB);
     accumulate<3>(accA, accB, r1, w);
-#endif
+  }
 }
 
 // pixel coordinates of a sample: floor, fractions, in-range test of cuh:285-288
@@ -223,12 +222,16 @@ __device__ __forceinline__ void corner_weights(float (&w)[4], const Pix &p, floa
     w[3] = al * p.lw;
 }
 
-template <int kTPW>
-__global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void msda_fwd_pyr2_d32(
+template <int kTPW, int kCfg>
+__global__ __launch_bounds__(kP2Configs[kCfg].threads, kP2Configs[kCfg].wgs_per_cu * kP2Configs[kCfg].threads / 256)
+void msda_fwd_pyr2_d32(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
     const Pyr2Meta pm, int S, int M, int nimg, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int kP2Threads = kP2Configs[kCfg].threads, kP2Waves = kP2Threads / 64;
+    // two samples' corner rows in flight where the register budget allows (168 VGPRs at 3 x 256 threads)
+    constexpr int kDepth = (kCfg == 1 || kTPW <= 2) ? 2 : 1;
     const int tid = threadIdx.x;
     const int nreg = pm.nRy * pm.nRx;
     const unsigned row_stride = (unsigned)M * kRowBytes;           // bytes between pixels of one head
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void ms
             const int wb = lbase + ((inwin ? wy : 0) * WW + (inwin ? wx : 0)) * kRowBytes;
             float w[4];
             corner_weights(w, p, use ? cur[t].a : 0.f);
-            lds_level(accA[t], accB[t], wb, w, chan, row_bytes);
+            lds_level<kDepth>(accA[t], accB[t], wb, w, chan, row_bytes);
 
             // ---- slow path (rare): samples outside their window come from global memory ----------
             if (__builtin_amdgcn_ballot_w64(miss) != 0) {
@@ -504,12 +507,13 @@ __global__ __launch_bounds__(kP2Threads, kP2WgsPerCu * kP2Threads / 256) void ms
 #endif
 }
 
-template <int kTPW>
+template <int kTPW, int kCfg>
 int launch(const float *value, const float *loc, const float *attn, const Pyr2Meta &pm, int64_t N,
            int64_t S, int64_t M, float *out, hipStream_t stream) {
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_fwd_pyr2_d32<kTPW>),
+    constexpr Pyr2Config cfg = kP2Configs[kCfg];
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_fwd_pyr2_d32<kTPW, kCfg>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    kP2LdsBytes) == hipSuccess;
+                                                    p2_lds_bytes(cfg)) == hipSuccess;
     if (!attr_ok) return DATR_EUNSUPPORTED;
 #if PYR2_BANDS
     const long blocks = (long)N * ((pm.nRy * pm.nRx + 7) / 8) * 8 * M;
@@ -517,10 +521,20 @@ int launch(const float *value, const float *loc, const float *attn, const Pyr2Me
     const long blocks = (long)N * pm.nRy * pm.nRx * M;
 #endif
     if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
-    hipLaunchKernelGGL(msda_fwd_pyr2_d32<kTPW>, dim3((unsigned)blocks), dim3(kP2Threads),
-                       (size_t)kP2WindowRows * kRowBytes, stream, value, loc, attn, pm, (int)S,
+    hipLaunchKernelGGL((msda_fwd_pyr2_d32<kTPW, kCfg>), dim3((unsigned)blocks), dim3(cfg.threads),
+                       (size_t)p2_window_rows(cfg) * kRowBytes, stream, value, loc, attn, pm, (int)S,
                        (int)M, (int)N, out);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+template <int kCfg>
+int launch_tpw(const float *value, const float *loc, const float *attn, const Pyr2Meta &pm, int64_t N,
+               int64_t S, int64_t M, float *out, hipStream_t st) {
+    switch (pm.tpw) {
+        case 1: case 2: return launch<2, kCfg>(value, loc, attn, pm, N, S, M, out, st);
+        case 3: return launch<3, kCfg>(value, loc, attn, pm, N, S, M, out, st);
+        default: return DATR_EUNSUPPORTED;
+    }
 }
 
 }  // namespace
@@ -561,7 +575,9 @@ extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, cons
     if (!hit) {
         memset(&pm, 0, sizeof(pm));
         static const char *force = getenv("DATR_MSDA_PYR2_REGIONS");
-        ok = build_pyr2_meta(pm, shapes_host, level_start_host, S, (int)M, env, force);
+        static const int force_cfg = (getenv("DATR_MSDA_PYR2_CONFIG") && *getenv("DATR_MSDA_PYR2_CONFIG"))
+                                         ? atoi(getenv("DATR_MSDA_PYR2_CONFIG")) : -1;
+        ok = build_pyr2_meta(pm, shapes_host, level_start_host, S, (int)M, env, force, force_cfg);
         Entry e;
         memcpy(e.sh, shapes_host, sizeof(e.sh));
         e.S = S; e.M = M; e.env = env; e.pm = pm; e.ok = ok;
@@ -570,7 +586,7 @@ extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, cons
         cache.push_back(e);
     }
     if (info) {
-        memset(info, 0, 8 * sizeof(int32_t));
+        memset(info, 0, 13 * sizeof(int32_t));
         if (ok) {
             int fill = 0, big = 0;
             for (int p = 0; p < pm.nph; ++p) {
@@ -582,6 +598,7 @@ extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, cons
             }
             info[0] = 1; info[1] = pm.nRy; info[2] = pm.nRx; info[3] = pm.nph; info[4] = pm.tpw;
             info[5] = pm.nRy * pm.nRx * (int)M; info[6] = fill / 8; info[7] = big;
+            info[12 - 8 + 8] = pm.config;        // [12]: launch configuration (index into kP2Configs)
         }
     }
     if (ok && pm_out) *pm_out = pm;
@@ -599,11 +616,6 @@ extern "C" int datr_internal_msda_fwd_pyr2_d32(
     const int rc = datr_internal_msda_fwd_pyr2_plan(shapes_host, level_start_host, S, M, envelope_host, &pm, nullptr);
     if (rc != DATR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    switch (pm.tpw) {
-        case 1: case 2: return launch<2>(value, loc, attn, pm, N, S, M, out, st);
-        case 3: if constexpr (kP2MaxTasks >= 3) return launch<3>(value, loc, attn, pm, N, S, M, out, st);
-        case 4: if constexpr (kP2MaxTasks >= 4) return launch<4>(value, loc, attn, pm, N, S, M, out, st);
-        case 5: case 6: if constexpr (kP2MaxTasks >= 6) return launch<6>(value, loc, attn, pm, N, S, M, out, st);
-        default: return DATR_EUNSUPPORTED;
-    }
+    return pm.config == 1 ? launch_tpw<1>(value, loc, attn, pm, N, S, M, out, st)
+                          : launch_tpw<0>(value, loc, attn, pm, N, S, M, out, st);
 }

@@ -25,25 +25,17 @@
 
 constexpr int kP2MaxR = 16;          // regions per axis
 constexpr int kP2Heads = 8;          // per-head tables
-#ifndef PYR2_THREADS
-#define PYR2_THREADS 512
-#endif
-#ifndef PYR2_MAX_TASKS
-#define PYR2_MAX_TASKS 3
-#endif
-// Two workgroups per CU.  The waves of a workgroup must spread EVENLY over the 4 SIMDs: with 384
+// Launch configurations.  The waves of a workgroup must spread EVENLY over the 4 SIMDs: with 384
 // threads (2,2,1,1 waves per SIMD) the second workgroup only fits beside the first when the
 // dispatcher happens to rotate its start SIMD -- measured: one workgroup per CU most of the time.
-constexpr int kP2Threads = PYR2_THREADS;
-constexpr int kP2Waves = kP2Threads / 64;
-constexpr int kP2MaxTasks = PYR2_MAX_TASKS;   // 16-query tasks per wave (static unroll of the accumulators)
-constexpr int kP2MaxQueries = kP2Waves * kP2MaxTasks * 16;   // 384
-#ifndef PYR2_WGS_PER_CU
-#define PYR2_WGS_PER_CU 2
-#endif
-constexpr int kP2WgsPerCu = PYR2_WGS_PER_CU;
-constexpr int kP2LdsBytes = (160 / kP2WgsPerCu) * 1024;      // per workgroup
-constexpr int kP2WindowRows = (kP2LdsBytes - 1024) / 128;     // 128-B rows per phase (632)
+//   config 0: 512 threads, two workgroups per CU (80 KB of windows each), <= 3 tasks per wave
+//   config 1: 256 threads, three per CU (53 KB each), <= 3 tasks per wave -- more independent
+//             workgroups to cover each other's fills; level with config 0 at best (DATR_MSDA_PYR2_CONFIG=1).
+struct Pyr2Config { int threads, wgs_per_cu, max_tasks; };
+constexpr Pyr2Config kP2Configs[2] = {{512, 2, 3}, {256, 3, 3}};
+constexpr int p2_waves(const Pyr2Config &c) { return c.threads / 64; }
+constexpr int p2_lds_bytes(const Pyr2Config &c) { return (160 / c.wgs_per_cu) * 1024; }
+constexpr int p2_window_rows(const Pyr2Config &c) { return (p2_lds_bytes(c) - 1024) / 128; }   // 128-B rows per phase
 
 // Every field the kernel indexes with a run-time (wave-uniform) index is a 32-bit word or an
 // aligned group of 16-bit words: hipcc turns those into s_load_dword(x2/x4) from the kernel
@@ -53,6 +45,7 @@ struct P2HeadLevel { int WH, WW, row0, pad; };           // window dims, first 1
 struct Pyr2Meta {
     int H[4], W[4], start[4];
     int nRy, nRx, nph, tpw;
+    int config, pad_[3];                                  // index into kP2Configs
     int ph_mask[4];                                      // levels staged in phase p (bit l)
     int yb[kP2MaxR + 1][4], xb[kP2MaxR + 1][4];          // [region index][level]: first query row / col
     P2HeadLevel hl[kP2Heads][4];
@@ -75,7 +68,8 @@ inline void p2_symmetric_envelope(Pyr2Envelope &e, float halo) {
 // Fills the geometry part of `pm` for the grid nRy x nRx; returns false when a level's window does
 // not fit a phase, a region has too many queries, or a dimension overflows its table type.
 // `cost` = estimated fill bytes of the whole launch per image (all heads), for the grid search.
-inline bool p2_try_grid(Pyr2Meta &pm, const Pyr2Envelope &env, int M, int nRy, int nRx, double *cost) {
+inline bool p2_try_grid(Pyr2Meta &pm, const Pyr2Config &cfg, const Pyr2Envelope &env, int M, int nRy, int nRx,
+                        double *cost) {
     pm.nRy = nRy; pm.nRx = nRx;
     for (int axis = 0; axis < 2; ++axis) {
         const int nR = axis ? nRx : nRy;
@@ -120,9 +114,9 @@ inline bool p2_try_grid(Pyr2Meta &pm, const Pyr2Envelope &env, int M, int nRy, i
                 c += (pm.yb[i + 1][l] - pm.yb[i][l]) * (pm.xb[k + 1][l] - pm.xb[k][l]);
             most = std::max(most, c);
         }
-    if (most > kP2MaxQueries) return false;
+    if (most > p2_waves(cfg) * cfg.max_tasks * 16) return false;
     const int ntasks = (most + 15) / 16;
-    pm.tpw = (ntasks + kP2Waves - 1) / kP2Waves;
+    pm.tpw = (ntasks + p2_waves(cfg) - 1) / p2_waves(cfg);
     // phases: the same level sets for every head (the largest head decides), greedy in level order
     int rows[kP2Heads][4], worst[4] = {0, 0, 0, 0};
     for (int m = 0; m < M; ++m)
@@ -133,8 +127,8 @@ inline bool p2_try_grid(Pyr2Meta &pm, const Pyr2Envelope &env, int M, int nRy, i
     int nph = 0, used = 0;
     memset(pm.ph_mask, 0, sizeof(pm.ph_mask));
     for (int l = 0; l < 4; ++l) {
-        if (worst[l] > kP2WindowRows) return false;
-        if (nph == 0 || used + worst[l] > kP2WindowRows) {
+        if (worst[l] > p2_window_rows(cfg)) return false;
+        if (nph == 0 || used + worst[l] > p2_window_rows(cfg)) {
             if (nph == 4) return false;
             ++nph;
             used = 0;
@@ -163,10 +157,34 @@ inline bool p2_try_grid(Pyr2Meta &pm, const Pyr2Envelope &env, int M, int nRy, i
     return true;
 }
 
-// Plan for a 4-level pyramid: searches the region grid with the least estimated fill traffic.
-// `force` = "RYxRX" (development) pins the grid.
+// Plan for a 4-level pyramid under one launch configuration: the region grid with the least
+// estimated cost.  `force` = "RYxRX" (development) pins the grid.
+inline bool build_pyr2_meta_cfg(Pyr2Meta &pm, int config, int M, const Pyr2Envelope &env, const char *force) {
+    const Pyr2Config &cfg = kP2Configs[config];
+    pm.config = config;
+    int fy = 0, fx = 0;
+    if (force && std::sscanf(force, "%dx%d", &fy, &fx) == 2 && fy >= 1 && fx >= 1 && fy <= kP2MaxR && fx <= kP2MaxR)
+        return p2_try_grid(pm, cfg, env, M, fy, fx, nullptr);
+    // Measured on the N = 4 call at 1333x800 (profiles/r03_msda_fwd.md, after the location loads lost
+    // their non-temporal hint): 8x12 111 us, 7x14 114, 5x12 (two phases) 117, 10x16 127, 12x16 133,
+    // 16x16 148 -- the least staged bytes win, an extra phase costs a good 15 %, one task per wave
+    // leaves the waves idle through the fills.
+    double best = 1e300;
+    int by = 0, bx = 0;
+    Pyr2Meta trial = pm;
+    for (int ry = 1; ry <= kP2MaxR; ++ry)
+        for (int rx = 1; rx <= kP2MaxR; ++rx) {
+            double c;
+            if (!p2_try_grid(trial, cfg, env, M, ry, rx, &c)) continue;
+            c *= 1.0 + 0.3 * (trial.nph - 1) + (trial.tpw < 2 ? 0.3 : 0.0);
+            if (c < best) { best = c; by = ry; bx = rx; }
+        }
+    if (!by) return false;
+    return p2_try_grid(pm, cfg, env, M, by, bx, nullptr);
+}
+
 inline bool build_pyr2_meta(Pyr2Meta &pm, const int64_t *sh, const int64_t *ls, int64_t S, int M,
-                            const Pyr2Envelope &env, const char *force = nullptr) {
+                            const Pyr2Envelope &env, const char *force = nullptr, int force_config = -1) {
     if (M < 1 || M > kP2Heads) return false;
     long total = 0;
     for (int l = 0; l < 4; ++l) {
@@ -178,24 +196,7 @@ inline bool build_pyr2_meta(Pyr2Meta &pm, const int64_t *sh, const int64_t *ls, 
     if (total != S || S * (long)M * 128 >= (1L << 31)) return false;
     for (int l = 1; l < 4; ++l)
         if (pm.H[l] > pm.H[l - 1] || pm.W[l] > pm.W[l - 1]) return false;
-    int fy = 0, fx = 0;
-    if (force && std::sscanf(force, "%dx%d", &fy, &fx) == 2 && fy >= 1 && fx >= 1 && fy <= kP2MaxR && fx <= kP2MaxR) {
-        return p2_try_grid(pm, env, M, fy, fx, nullptr);
-    }
-    // Measured on the N = 4 call at 1333x800 (profiles/r03_msda_fwd.md, after the location loads lost
-    // their non-temporal hint): 8x12 111 us, 7x14 114, 5x12 (two phases) 117, 10x16 127, 12x16 133,
-    // 16x16 148 -- the least staged bytes win, an extra phase costs about 15 %, one task per wave
-    // leaves the waves idle through the fills.
-    double best = 1e300;
-    int by = 0, bx = 0;
-    Pyr2Meta trial = pm;
-    for (int ry = 1; ry <= kP2MaxR; ++ry)
-        for (int rx = 1; rx <= kP2MaxR; ++rx) {
-            double c;
-            if (!p2_try_grid(trial, env, M, ry, rx, &c)) continue;
-            c *= 1.0 + 0.3 * (trial.nph - 1) + (trial.tpw < 2 ? 0.3 : 0.0);
-            if (c < best) { best = c; by = ry; bx = rx; }
-        }
-    if (!by) return false;
-    return p2_try_grid(pm, env, M, by, bx, nullptr);
+    // configuration 1 (three 256-thread workgroups per CU) measured level with configuration 0 on
+    // the ring envelope (113.6 vs 114.6 us) and behind it for wider ones (158 vs 149 us): development only
+    return build_pyr2_meta_cfg(pm, force_config >= 0 ? (force_config & 1) : 0, M, env, force);
 }

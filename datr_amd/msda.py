@@ -104,7 +104,7 @@ def pyramid_plan(spatial_shapes, level_start_index, N, M, D, P, envelope=None):
     _native.check(rc, "pyramid_plan")
     return {"forward": bool(info[0]), "grid": (int(info[1]), int(info[2])), "phases": int(info[3]),
             "tasks_per_wave": int(info[4]), "workgroups_per_image": int(info[5]), "fill_kib": int(info[6]),
-            "largest_phase_rows": int(info[7]), "phased": bool(info[11]), "backward": bool(info[8]),
+            "largest_phase_rows": int(info[7]), "phased": bool(info[11]), "config": int(info[12]), "backward": bool(info[8]),
             "backward_grid": (int(info[9]), int(info[10]))}
 
 

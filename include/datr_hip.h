@@ -124,7 +124,7 @@ int datr_msda_forward_pyramid_f32(const float *value, const int64_t *shapes,
  * [3] phases, [4] 16-query tasks per wave, [5] workgroups per image, [6] LDS fill KiB per workgroup
  * (head 0), [7] largest phase in 128-B rows (head 0); [8] backward covered by the pyramid-region
  * kernel, [9] nRy, [10] nRx; [11] datr_msda_forward_pyramid_f32 would run the phased kernel (it does
- * whenever [0] is set); rest 0. */
+ * whenever [0] is set); [12] launch configuration (0: 512 threads x 2 workgroups per CU, 1: 256 x 3); rest 0. */
 int datr_msda_pyramid_plan(const int64_t *shapes_host, const int64_t *level_start_host, int64_t N,
                            int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
                            const float *envelope_host, int32_t *info);
