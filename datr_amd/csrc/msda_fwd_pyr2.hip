@@ -237,6 +237,11 @@ void msda_fwd_pyr2_d32(
     const unsigned row_stride = (unsigned)M * kRowBytes;           // bytes between pixels of one head
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PYR2_PROBE
+    unsigned long long ticks_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = __builtin_readcyclecounter();
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), cy0_ = tick_;
+#endif
     {
     const int item = blockIdx.x;      // one (image, region, head) item per workgroup, head fastest:
                                       // workgroup b runs on XCD b % 8, an XCD's L2 holds one head's slice
