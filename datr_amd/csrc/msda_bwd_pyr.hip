@@ -59,6 +59,9 @@ extern "C" void datr_probe_pyr_bwd_phase_cycles(unsigned long long *out, int res
 
 namespace {
 
+#ifndef PYRB_INFLIGHT
+#define PYRB_INFLIGHT 8
+#endif
 #ifndef PYRB_BANDS
 #define PYRB_BANDS 0
 #endif
@@ -75,13 +78,16 @@ constexpr int kMaxRows = 1024;             // rows of a level's window
 constexpr int kMaxTasks = (kMaxQ / 16 + kWaves - 1) / kWaves;      // 16-query tasks per wave: 3
 constexpr unsigned kOutOfRange = 0x80000000u;
 constexpr int kRowBytes = 128;
+constexpr int kInFlight = PYRB_INFLIGHT;    // records of a row in flight in the reduce phase
 
 // LDS map (bytes)
 constexpr int kGoOff = 0;                                  // grad_out rows by query slot
 constexpr int kRecOff = kGoOff + kMaxQ * kRowBytes;        // records of the current level
 constexpr int kHistOff = kRecOff + kMaxQ * 16 * 8;         // counts -> exclusive offsets [rows + 1]
-constexpr int kCurOff = kHistOff + (2 * kThreads) * 4;     // cursors
-constexpr int kTabOff = kCurOff + (2 * kThreads) * 4;      // query slot -> pyramid index
+constexpr int kCurOff = kHistOff + (2 * kThreads) * 4;     // cursors (pass B); in the reduce phase: flush scratch
+constexpr int kFlushPerWave = 8 * kRowBytes + 8 * 4;       // 8 finished rows + their global offsets
+constexpr int kCurBytes = (2 * kThreads) * 4 > kWaves * kFlushPerWave ? (2 * kThreads) * 4 : kWaves * kFlushPerWave;
+constexpr int kTabOff = kCurOff + ((kCurBytes + 15) & ~15);   // query slot -> pyramid index
 constexpr int kScanOff = kTabOff + kMaxQ * 4;              // per-wave totals of the scan
 constexpr int kLdsBytes = kScanOff + 64;
 static_assert(kMaxRows + 1 <= 2 * kThreads || true, "the scan gives every thread two histogram entries");
@@ -360,40 +366,65 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
         TICK(2);
 
         // ---- reduce: a window row's gradient is a gather over its records -----------------------
+        // 8 lanes x float4 accumulate a row; the finished rows of a wave (8 at a time) are then
+        // TRANSPOSED through a 1 KB LDS scratch so that 32 consecutive lanes add 32 consecutive
+        // dwords: float atomics retire per (instruction, 64-byte segment) -- ~20 G such requests/s
+        // chip-wide (profiles/r01_probes.md) -- and the float4-per-lane pattern (lane stride 16 B, one
+        // component per instruction) made 8 requests per row where this makes 2.  At ~1.65 M touched
+        // rows per N = 4 call that was 13 M requests = 0.66 ms of the kernel's 0.75 ms.
         {
-            const int grp = tid >> 3, c8 = tid & 7;
-            for (int r = grp; r < rows; r += kThreads / 8) {
-                const unsigned beg = hist[r], end = hist[r + 1];
-                if (beg == end) continue;
+            const int grp = tid >> 3, c8 = tid & 7, g8 = lane >> 3;
+            char *fl = lds + kCurOff + wave * kFlushPerWave;
+            unsigned *fl_off = reinterpret_cast<unsigned *>(fl + 8 * kRowBytes);
+            const int rounds = (rows + kThreads / 8 - 1) / (kThreads / 8);
+            for (int it = 0; it < rounds; ++it) {
+                const int r = grp + it * (kThreads / 8);
+                unsigned beg = 0, end = 0;
+                if (r < rows) { beg = hist[r]; end = hist[r + 1]; }
                 f4 acc = {0.f, 0.f, 0.f, 0.f};
-                // four records in flight: record read -> grad_out row read -> FMA is a chain of
+                // kInFlight records in flight: record read -> grad_out row read -> FMA is a chain of
                 // two LDS latencies, so the loop is unrolled to keep several chains going
-                for (unsigned e = beg; e < end; e += 4) {
-                    unsigned long long rec[4];
-                    f4 g_[4];
-                    float w_[4];
+                for (unsigned e = beg; e < end; e += kInFlight) {
+                    unsigned long long rec[kInFlight];
+                    f4 g_[kInFlight];
+                    float w_[kInFlight];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) rec[u] = recs[min(e + u, end - 1)];
+                    for (int u = 0; u < kInFlight; ++u) rec[u] = recs[min(e + u, end - 1)];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kInFlight; ++u) {
                         w_[u] = e + u < end ? __uint_as_float((unsigned)(rec[u] >> 32)) : 0.f;
                         g_[u] = *reinterpret_cast<const f4 *>(
                             lds + kGoOff + (int)(rec[u] & 0xffffffffull) * kRowBytes + c8 * 16);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kInFlight; ++u) {
                         acc.x = fmaf(w_[u], g_[u].x, acc.x);
                         acc.y = fmaf(w_[u], g_[u].y, acc.y);
                         acc.z = fmaf(w_[u], g_[u].z, acc.z);
                         acc.w = fmaf(w_[u], g_[u].w, acc.w);
                     }
                 }
-                const int wy = r / WW, wx = r - wy * WW;
-                const unsigned o_ = (unsigned)(stl + (wy0 + wy) * Wl + wx0 + wx) * row_stride + (unsigned)c8 * 16u;
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.x, gsrc, o_, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.y, gsrc, o_ + 4, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.z, gsrc, o_ + 8, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc.w, gsrc, o_ + 12, 0, 0);
+                if (__builtin_amdgcn_ballot_w64(beg != end) == 0) continue;      // wave-uniform: nothing to flush
+                *reinterpret_cast<f4 *>(fl + g8 * kRowBytes + c8 * 16) = acc;
+                if (c8 == 0) {
+                    const int wy = r / WW, wx = r - wy * WW;
+                    fl_off[g8] = beg != end ? (unsigned)(stl + (wy0 + wy) * Wl + wx0 + wx) * row_stride : kOutOfRange;
+                }
+                // same wave wrote and reads: LDS operations of a wave complete in order; the fences keep
+                // the compiler from moving the cross-lane reads above the writes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int g = 2 * k + (lane >> 5), l32 = lane & 31;
+                    const unsigned o_ = fl_off[g];
+                    const float v = *reinterpret_cast<const float *>(fl + g * kRowBytes + l32 * 4);
+                    // an empty row has the out-of-range offset: the buffer atomic is dropped
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, gsrc, o_ + (unsigned)l32 * 4u, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();      // the scratch is rewritten by the next round
             }
         }
         TICK(4);                               // reduce + flush
