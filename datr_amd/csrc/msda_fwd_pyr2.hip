@@ -246,14 +246,15 @@ void msda_fwd_pyr2_d32(
     const int item = blockIdx.x;      // one (image, region, head) item per workgroup, head fastest:
                                       // workgroup b runs on XCD b % 8, an XCD's L2 holds one head's slice
 #if PYR2_BANDS
-    // XCD = item % 8 owns a BAND of regions with all heads (dense lines in its L2) instead of one head
-    // everywhere (every 8th 128-B line): item = ((j * M + m) * 8 + band) within an image
-    const int per_band = (nreg + 7) / 8;
-    const int n = item / (8 * per_band * M);
-    const int rem = item - n * (8 * per_band * M);
-    const int band = rem % 8, m = (rem / 8) % M, jj = rem / (8 * M);
-    const int reg = band * per_band + jj;
-    if (reg >= nreg) return;
+    // XCD = item % 8 owns a BAND of (image, region) pairs with all heads (dense lines in its L2)
+    // instead of one head everywhere (every 8th 128-B line): item = (j * M + m) * 8 + band.
+    // Bands run over the pairs of the whole launch: 4 x 98 regions are 49 pairs per XCD, where
+    // per-image bands of ceil(98 / 8) = 13 regions left the eighth XCD half idle.
+    const int npair = nimg * nreg;
+    const int band = item % 8, m = (item / 8) % M, jj = item / (8 * M);
+    const int pair = band * npair / 8 + jj;                 // band b: pairs [b npair / 8, (b + 1) npair / 8)
+    if (pair >= (band + 1) * npair / 8) return;
+    const int n = pair / nreg, reg = pair - n * nreg;
     const int ry = reg / pm.nRx, rx = reg % pm.nRx;
 #else
     const int m = item % M;
@@ -521,7 +522,7 @@ int launch(const float *value, const float *loc, const float *attn, const Pyr2Me
                                                     p2_lds_bytes(cfg)) == hipSuccess;
     if (!attr_ok) return DATR_EUNSUPPORTED;
 #if PYR2_BANDS
-    const long blocks = (long)N * ((pm.nRy * pm.nRx + 7) / 8) * 8 * M;
+    const long blocks = ((long)N * pm.nRy * pm.nRx + 7) / 8 * 8 * M;
 #else
     const long blocks = (long)N * pm.nRy * pm.nRx * M;
 #endif
