@@ -71,9 +71,9 @@ _SIGNATURES = {
     "datr_wino_weights_f32": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
     "datr_conv3x3_wino_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, _vp],
-    "datr_conv_s2_forward_nhwc_f32": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_i64] * 6 + [_vp, _vp, _i64, _vp],
-    "datr_conv_s2_dgrad_nhwc_f32": [_vp, _vp] + [_i64] * 6 + [_vp, _vp, _i64, _vp],
-    "datr_conv_s2_wgrad_nhwc_f32": [_vp, _vp] + [_i64] * 6 + [_vp] + [_i64] * 4 + [_vp, _i64, _vp],
+    "datr_conv3x3s2_forward_nhwc_f32": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_i64] * 5 + [_vp, _vp, _i64, _vp],
+    "datr_conv3x3s2_dgrad_nhwc_f32": [_vp, _vp] + [_i64] * 5 + [_vp, _vp, _i64, _vp],
+    "datr_conv3x3s2_wgrad_nhwc_f32": [_vp, _vp] + [_i64] * 5 + [_vp] + [_i64] * 4 + [_vp, _i64, _vp],
     "datr_conv3x3_cout1_forward_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "datr_conv3x3_cout1_backward_f32": [_vp, _i64, _i64, _i64, _vp, ctypes.c_float, _vp, _vp, _vp, _vp],
     "datr_focal_loss_forward_f32": [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
@@ -124,8 +124,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_groupnorm_partial_floats.argtypes = [_i64, _i64, _i64, _i64]
     lib.datr_wino_wgrad_partial_floats.restype = ctypes.c_int64
     lib.datr_wino_wgrad_partial_floats.argtypes = [_vp, _i64, _i64, _i64, _i64]
-    lib.datr_conv_s2_workspace_floats.restype = ctypes.c_int64
-    lib.datr_conv_s2_workspace_floats.argtypes = [_i64] * 6
+    lib.datr_conv3x3s2_workspace_floats.restype = ctypes.c_int64
+    lib.datr_conv3x3s2_workspace_floats.argtypes = [_i64] * 5
     lib.datr_conv3x3_cout1_partial_floats.restype = ctypes.c_int64
     lib.datr_conv3x3_cout1_partial_floats.argtypes = [_vp, _i64, _i64]
     lib.datr_ema_piece_elements.restype = ctypes.c_int64

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .fused import frozen_bn_act
+from . import strided
 from .wino import conv3x3_bn_relu, conv3x3_own_wgrad
 from . import pointwise
 from .nested import NestedTensor
@@ -98,8 +99,12 @@ class Bottleneck(nn.Module):
             identity = x
         else:
             identity = None
-            if nhwc and ds_conv.stride == (1, 1) and folded is not None and folded[1] is not None:
-                identity = pointwise.conv1x1(x, folded[1], self.downsample[1].scale_shift()[1])
+            if nhwc and folded is not None and folded[1] is not None:
+                shift_ds = self.downsample[1].scale_shift()[1]
+                if ds_conv.stride == (1, 1):
+                    identity = pointwise.conv1x1(x, folded[1], shift_ds)
+                elif ds_conv.stride == (2, 2):           # even pixels gathered, then the same GEMM
+                    identity = strided.conv1x1_s2(x, folded[1], shift_ds)
             if identity is None:
                 identity = frozen_bn_act(ds_conv(x), *self.downsample[1].scale_shift(), relu=False)
         out = None
@@ -115,6 +120,9 @@ class Bottleneck(nn.Module):
                 y2 = conv3x3_own_wgrad(out, self.conv2.weight)
                 if y2 is not None:
                     out2 = frozen_bn_act(y2, *self.bn2.scale_shift(), relu=True)
+        elif nhwc and self.conv2.stride == (2, 2):
+            # 3x3 / stride 2 + frozen BN + ReLU: the tap-list MFMA kernels (csrc/conv_tap.hip)
+            out2 = strided.conv3x3_s2(out, self.conv2.weight, *self.bn2.scale_shift(), relu=True)
         out = out2 if out2 is not None else frozen_bn_act(self.conv2(out), *self.bn2.scale_shift(), relu=True)
         y3 = pointwise.conv1x1(out, self.conv3.weight) if nhwc else None
         if y3 is None:
@@ -123,9 +131,9 @@ class Bottleneck(nn.Module):
 
     def fold_pairs(self):
         """(weight, frozen scale) of the 1x1 convolutions whose batch norm is folded into the GEMM:
-        conv1 and, when it has stride 1, the downsample convolution."""
+        conv1 and the downsample convolution."""
         pairs = [(self.conv1.weight, self.bn1.scale_shift()[0])]
-        if self.downsample is not None and self.downsample[0].stride == (1, 1):
+        if self.downsample is not None and self.downsample[0].stride in ((1, 1), (2, 2)):
             pairs.append((self.downsample[0].weight, self.downsample[1].scale_shift()[0]))
         return pairs
 
@@ -180,8 +188,8 @@ class _StageOutputs(nn.ModuleDict):
         self.return_layers = dict(return_layers)
 
     def _fold_bottlenecks(self, x):
-        """Frozen-BN scales folded into the weights of every bottleneck's conv1 (and stride-1
-        downsample convolution) for this forward pass -- ONE multi-tensor multiply for the whole
+        """Frozen-BN scales folded into the weights of every bottleneck's conv1 (and downsample
+        convolution) for this forward pass -- ONE multi-tensor multiply for the whole
         trunk (datr_amd.pointwise.fold_frozen_bn); blocks read their share from `_folded`."""
         blocks = [m for m in self.modules() if isinstance(m, Bottleneck)]
         live = (pointwise.GEMM_1X1 and x.is_cuda and x.dtype == torch.float32

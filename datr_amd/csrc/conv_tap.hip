@@ -33,6 +33,8 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 
 #include "datr_hip.h"
 
@@ -44,7 +46,6 @@ constexpr int kThreads = 256;
 constexpr int TH = 8, TW = 16;                 // positions per workgroup
 constexpr int CK = 16;                         // input channels per chunk
 constexpr int PSTR = 20;                       // patch pixel stride in floats (16 + 4 pad)
-constexpr int BN = 128;                        // output channels per workgroup
 constexpr int kMaxTaps = 9;
 
 struct TapArgs {
@@ -61,13 +62,32 @@ struct TapArgs {
     float slope;
 };
 
-template <int IS>
+constexpr int kSlabs = 4;                      // weight-slab ring: two (tap, chunk) steps in flight
+constexpr int kPatchLoads = 9;                 // float4 per thread that cover the largest patch (17 x 33 x 4 / 256)
+
+// s_waitcnt vmcnt(n) with a run-time n (the immediate is static)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define DATR_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+        DATR_W(0) DATR_W(1) DATR_W(2) DATR_W(3) DATR_W(4) DATR_W(5) DATR_W(6) DATR_W(7) DATR_W(8) DATR_W(9)
+        DATR_W(10) DATR_W(11) DATR_W(12)
+#undef DATR_W
+        default: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    }
+}
+
+template <int IS, int BNT>                      // BNT = output channels per workgroup (128)
 __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;                                            // PH * planes * PW2 * PSTR
+    // Dynamic LDS (it starts at address 0: the kernel has no static LDS), addressed through plain
+    // integers: with pointers into one array the compiler assumes every slab read may alias the
+    // LDS-DMA in flight and waits for vmcnt(0) in front of each.
+    //   patch  [PH * planes * PW2][PSTR] floats at 0;  slabs [kSlabs][CK][BN] floats behind it
     constexpr int planes = IS;
-    float (*wsl)[CK][BN] = reinterpret_cast<float (*)[CK][BN]>(smem + ((a.PH * planes * a.PW2 * PSTR + 3) & ~3));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef __attribute__((address_space(3))) f4 lds_f4;
+    const unsigned slab0 = (unsigned)((a.PH * planes * a.PW2 * PSTR + 3) & ~3) * 4u;     // bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -76,43 +96,67 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
     const int n = b;
-    const int co0 = blockIdx.y * BN;
+    constexpr int NJ = BNT / 64;                // 32-column accumulator tiles per wave
+    constexpr int kSlabInstr = BNT / 64;        // LDS-DMA instructions per wave and slab (1 KB each)
+    const int co0 = blockIdx.y * BNT;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const float *Xn = a.x + (size_t)n * a.Hin * a.Win * a.Cin;
     const int Cin = a.Cin, Cout = a.Cout;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
-    // weight slab [CK][BN] of (tap, chunk): 16 rows of 512 contiguous bytes -> LDS by LDS-DMA
+    // weight slab [CK][BNT] of (tap, chunk): 16 rows of BNT contiguous floats -> LDS by LDS-DMA
+    // (1 KB per wave instruction, no staging registers)
     auto dma_w = [&](int w, int ci0, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = (wave * 2 + u) * 2 + (lane >> 5);            // 0..15
-            const float *src = a.wt + ((size_t)w * Cin + ci0 + row) * Cout + co0 + (lane & 31) * 4;
+        for (int u = 0; u < kSlabInstr; ++u) {
+            const int e0 = (wave * kSlabInstr + u) * 256;                 // first float of this instruction's 1 KB
+            const int e = e0 + lane * 4;
+            const int row = e / BNT, col = e % BNT;
+            const float *src = a.wt + ((size_t)w * Cin + ci0 + row) * Cout + co0 + col;
             __builtin_amdgcn_global_load_lds(
                 (__attribute__((address_space(1))) const void *)src,
-                (__attribute__((address_space(3))) void *)&wsl[buf][(wave * 2 + u) * 2][0], 16, 0, 0);
+                (__attribute__((address_space(3))) void *)(uintptr_t)(slab0 + (unsigned)(buf * CK * BNT + e0) * 4u),
+                16, 0, 0);
         }
     };
+    // The input patch of a chunk: every thread fetches kPatchLoads float4 through a buffer descriptor
+    // (pixels outside the image or past the patch get an out-of-range offset and read zeros: the
+    // SAME number of loads for every thread and chunk, so the waits below can count them), one chunk
+    // ahead into registers, and writes them to LDS when the chunk is switched.
     const int PH = a.PH, PW = a.PW, PW2 = a.PW2;
     const int gy0 = oy0 * IS + a.mindy, gx0 = ox0 * IS + a.mindx;
-    auto load_patch = [&](int ci0) {
-        for (int f = tid; f < PH * PW * 4; f += kThreads) {
-            const int pix = f >> 2, q = f & 3;
-            const int pr = pix / PW, pc = pix - pr * PW;
-            const int yy = gy0 + pr, xx = gx0 + pc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win)
-                v = *reinterpret_cast<const float4 *>(Xn + ((size_t)yy * a.Win + xx) * Cin + ci0 + q * 4);
-            const int at = IS == 2 ? ((pr * 2 + (pc & 1)) * PW2 + (pc >> 1)) : (pr * PW2 + pc);
-            *reinterpret_cast<float4 *>(&patch[at * PSTR + q * 4]) = v;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x + (size_t)n * a.Hin * a.Win * Cin), 0, a.Hin * a.Win * Cin * 4, 0x00020000);
+    int poff[kPatchLoads], pat[kPatchLoads];
+#pragma unroll
+    for (int u = 0; u < kPatchLoads; ++u) {
+        const int f = tid + u * kThreads;
+        const int pix = f >> 2, q = f & 3;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int yy = gy0 + pr, xx = gx0 + pc;
+        const bool in = f < PH * PW * 4 && yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win;
+        poff[u] = in ? ((yy * a.Win + xx) * Cin + q * 4) * 4 : (int)0x80000000;
+        const int at = IS == 2 ? ((pr * 2 + (pc & 1)) * PW2 + (pc >> 1)) : (pr * PW2 + pc);
+        pat[u] = f < PH * PW * 4 ? at * PSTR + q * 4 : -1;
+    }
+    f4 pre[kPatchLoads];
+    auto fetch_patch = [&](int ci0) {
+#pragma unroll
+        for (int u = 0; u < kPatchLoads; ++u) {
+            const auto r = __builtin_amdgcn_raw_buffer_load_b128(xr, poff[u], ci0 * 4, 0);
+            pre[u] = __builtin_bit_cast(f4, r);
         }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int u = 0; u < kPatchLoads; ++u)
+            if (pat[u] >= 0) *reinterpret_cast<lds_f4 *>((unsigned)pat[u] * 4u) = pre[u];
     };
 
     // A-operand base of pixel block i of this wave: rows 2 i, 2 i + 1 of its 4 position rows
@@ -126,49 +170,73 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
     const int nchunks = Cin / CK;
     const int ch0 = (int)((long)blockIdx.z * nchunks / a.ksplit), ch1 = (int)((long)(blockIdx.z + 1) * nchunks / a.ksplit);
     const int ntaps = a.ntaps;
-    int step = 0;
-    if (ch0 < ch1) dma_w(a.widx[0], ch0 * CK, 0);
+    const int nsteps = (ch1 - ch0) * ntaps;
+    // step s = (chunk ch0 + s / ntaps, tap s % ntaps); its slab lives in ring slot s % kSlabs
+    auto issue_slab = [&](int s) {
+        const int c = s / ntaps, t = s - c * ntaps;
+        dma_w(a.widx[t], (ch0 + c) * CK, s % kSlabs);
+    };
+    fetch_patch(ch0 * CK);
+    if (nsteps > 0) issue_slab(0);
+    if (nsteps > 1) issue_slab(1);
+    wait_vm(0);
+    store_patch();
+    int s = 0;
     for (int ch = ch0; ch < ch1; ++ch) {
-        const int ci0 = ch * CK;
-        __syncthreads();                        // previous chunk's readers are done with the patch
-        load_patch(ci0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
 #pragma unroll 1
-        for (int t = 0; t < ntaps; ++t, ++step) {
-            const int buf = step & 1;
-            const bool last_tap = t + 1 == ntaps;
-            const bool more = !last_tap || ch + 1 < ch1;
-            if (more) dma_w(a.widx[last_tap ? 0 : t + 1], last_tap ? ci0 + CK : ci0, buf ^ 1);
+        for (int t = 0; t < ntaps; ++t, ++s) {
+            // Vector-memory operations of a thread, in issue order:
+            //   ... slab(s) | slab(s + 1) | [patch(ch + 1) at t == 0, after this step's wait] | slab(s + 2) ...
+            // slab(s) has landed once at most the operations issued after it are outstanding.
+            const bool s1 = s + 1 < nsteps, s2 = s + 2 < nsteps;
+            if (s2) issue_slab(s + 2);
+            const bool patch_in_flight = (t == 1 || t == 2) && ch + 1 < ch1 && ntaps > t;
+            wait_vm((s1 ? kSlabInstr : 0) + (s2 ? kSlabInstr : 0) + (patch_in_flight ? kPatchLoads : 0));
+            // everybody's part of slab(s) (and, at t == 0, of the patch); NOT __syncthreads(): its fence
+            // waits for vmcnt(0), i.e. for the slabs in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t == 0 && ch + 1 < ch1) fetch_patch((ch + 1) * CK);
+            const int buf = s % kSlabs;
             const int toff = a.toff[t];
 #pragma unroll
             for (int grp = 0; grp < 2; ++grp) {          // two 8-channel groups of the chunk
-                float4 av[2];
+                f4 av[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    av[i] = *reinterpret_cast<const float4 *>(&patch[abase[i] + toff + grp * 8]);
+                    av[i] = *reinterpret_cast<const lds_f4 *>((unsigned)(abase[i] + toff + grp * 8) * 4u);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int k = grp * 8 + lhi * 4 + s;
-                    const float b0 = wsl[buf][k][wn * 64 + l31];
-                    const float b1 = wsl[buf][k][wn * 64 + 32 + l31];
-                    const float a0 = s == 0 ? av[0].x : s == 1 ? av[0].y : s == 2 ? av[0].z : av[0].w;
-                    const float a1 = s == 0 ? av[1].x : s == 1 ? av[1].y : s == 2 ? av[1].z : av[1].w;
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    const int k = grp * 8 + lhi * 4 + q;
+                    const unsigned bo = slab0 + (unsigned)((buf * CK + k) * BNT + wn * (BNT / 2) + l31) * 4u;
+                    const float a0 = q == 0 ? av[0].x : q == 1 ? av[0].y : q == 2 ? av[0].z : av[0].w;
+                    const float a1 = q == 0 ? av[1].x : q == 1 ? av[1].y : q == 2 ? av[1].z : av[1].w;
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) {
+                        const float bv = *reinterpret_cast<const lds_f *>(bo + 128u * jn);
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][jn], 0, 0, 0);
+                        acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][jn], 0, 0, 0);
+                    }
                 }
             }
-            if (more && !last_tap) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next slab landed (this wave's part)
-                __syncthreads();
-            }
+        }
+        if (ch + 1 < ch1) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the chunk's readers are done with the patch
+            store_patch();                      // (the compiler waits for the prefetched registers here)
         }
     }
 
     // ---- epilogue: 32 lanes = 32 consecutive output channels (128 B) -----------------------------
     const bool raw = a.ksplit > 1;
+    float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
+    if (!raw) {
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            const int c = co0 + wn * (BNT / 2) + jn * 32 + l31;
+            if (a.scale) sc[jn] = a.scale[c];
+            if (a.shift) sh[jn] = a.shift[c];
+        }
+    }
+    const float slope = raw ? 1.f : a.slope;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -182,16 +250,11 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
                     yb = a.y + ((((size_t)blockIdx.z * gridDim.x / (a.tiles_x * a.tiles_y) + n) * a.Hidx + oy) * a.Widx + ox) * Cout;
                 else
                     yb = a.y + (((size_t)n * a.Hout + oy * a.OS + a.OOy) * a.Wout + ox * a.OS + a.OOx) * Cout;
-                yb += co0 + wn * 64 + l31;
+                yb += co0 + wn * (BNT / 2) + l31;
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
-                    float v = acc[i][jn][e];
-                    if (!raw) {
-                        const int c = co0 + wn * 64 + jn * 32 + l31;
-                        if (a.scale) v *= a.scale[c];
-                        if (a.shift) v += a.shift[c];
-                        v = v > 0.f ? v : v * a.slope;
-                    }
+                for (int jn = 0; jn < NJ; ++jn) {
+                    float v = acc[i][jn][e] * sc[jn] + sh[jn];
+                    v = v > 0.f ? v : v * slope;
                     yb[jn * 32] = v;
                 }
             }
@@ -228,13 +291,24 @@ __global__ __launch_bounds__(256) void tap_fold(const float *__restrict__ partia
         make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// split K when the tiles do not fill the machine (deterministic: partial sums + fold)
-int pick_ksplit(long N, long Hidx, long Widx, long Cin, long Cout) {
-    const long wgs = N * ((Widx + TW - 1) / TW) * ((Hidx + TH - 1) / TH) * (Cout / BN);
+// K split of a launch.  The tiles of a map are few (4 x 50 x 84 outputs = 168 tiles x 2 channel blocks)
+// and a CU's matrix pipes are shared by its two resident workgroups: 336 workgroups leave 176 CUs with
+// one workgroup (done in half the time, then idle) -- measured 357 us against 286 us with K split
+// in two (672 workgroups) for layer3.0.conv2; 401 -> 279 us with K split in four for layer4.0.conv2
+// (192 tiles); splitting further, or 64-channel workgroups instead, was slower (tools/probes/
+// conv_tap_plans.sh).  The partial sums are added in a fixed order (tap_fold).
+struct TapPlan { int bn, ksplit; };
+TapPlan pick_plan(long N, long Hidx, long Widx, long Cin, long Cout, int ntaps) {
+    (void)ntaps;
+    const long wgs = N * ((Widx + TW - 1) / TW) * ((Hidx + TH - 1) / TH) * (Cout / 128);
     const long nchunks = Cin / CK;
-    int ksplit = 1;
-    while (wgs * ksplit < 384 && ksplit * 2 <= nchunks / 4 && ksplit < 16) ksplit *= 2;
-    return ksplit;
+    if (const char *f = getenv("DATR_TAP_PLAN")) {          // development: "128,ksplit"
+        int bn = 0, ks = 0;
+        if (sscanf(f, "%d,%d", &bn, &ks) == 2 && bn == 128 && ks >= 1 && ks <= 16 && ks <= nchunks) return TapPlan{bn, ks};
+    }
+    int ks = 1;
+    while (wgs * ks < 512 && ks * 2 <= nchunks / 2 && ks < 16) ks *= 2;
+    return TapPlan{128, ks};
 }
 
 int launch_taps(int IS, const float *x, const float *wt, const float *scale, const float *shift, float slope,
@@ -263,21 +337,24 @@ int launch_taps(int IS, const float *x, const float *wt, const float *scale, con
         a.toff[t] = IS == 2 ? ((ddy * 2 + (ddx & 1)) * a.PW2 + (ddx >> 1)) * PSTR : (ddy * a.PW2 + ddx) * PSTR;
         a.widx[t] = taps[t][2];
     }
-    int ksplit = pick_ksplit(N, Hidx, Widx, Cin, Cout);
+    const TapPlan plan = pick_plan(N, Hidx, Widx, Cin, Cout, ntaps);
+    int ksplit = plan.ksplit;
+    const int bn = plan.bn;
     const long per_split = (long)N * Hidx * Widx * Cout;
     if (ksplit > 1 && (!partial || partial_floats < per_split * ksplit)) ksplit = 1;
     a.ksplit = ksplit;
     a.y = ksplit > 1 ? partial : y;
-    const size_t lds = (size_t)(((a.PH * IS * a.PW2 * PSTR + 3) & ~3) + 2 * CK * BN) * sizeof(float);
-    dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y), (unsigned)(Cout / BN), (unsigned)ksplit);
-    if (IS == 2) {
-        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(tap_conv<2>),
+    const size_t lds = (size_t)(((a.PH * IS * a.PW2 * PSTR + 3) & ~3) + kSlabs * CK * bn) * sizeof(float);
+    dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y), (unsigned)(Cout / bn), (unsigned)ksplit);
+    auto go = [&](auto kernel) {
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-        if (!ok) return DATR_EUNSUPPORTED;
-        hipLaunchKernelGGL(tap_conv<2>, grid, dim3(kThreads), lds, st, a);
-    } else {
-        hipLaunchKernelGGL(tap_conv<1>, grid, dim3(kThreads), lds, st, a);
-    }
+        if (!ok) return false;
+        hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, a);
+        return true;
+    };
+    const bool launched = IS == 2 ? go(tap_conv<2, 128>) : go(tap_conv<1, 128>);
+    if (!launched) return DATR_EUNSUPPORTED;
     if (ksplit > 1) {
         const long n4 = per_split / 4;
         hipLaunchKernelGGL(tap_fold, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, partial, ksplit, per_split,
@@ -298,13 +375,11 @@ struct WgradArgs {
     float *partial;
     int N, Hin, Win, Cin, Ho, Wo, Cout;
     int tiles_x, tiles_y, slices;
-    int ksize;                                  // 3 (pad 1) or 1 (pad 0); stride 2
 };
 
-template <int KS>
 __global__ __launch_bounds__(kThreads, 2) void tap_wgrad(const WgradArgs a)
 {
-    constexpr int NT = KS * KS;
+    constexpr int KS = 3, NT = KS * KS;
     constexpr int PH = (WTH - 1) * 2 + KS, PW = (WTW - 1) * 2 + KS;
     constexpr int pad = KS / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -378,10 +453,11 @@ __global__ __launch_bounds__(kThreads, 2) void tap_wgrad(const WgradArgs a)
 }
 
 // dw[co][ci][r][s] = sum over slices; a thread per (ci, co) with co fastest in the partials
-__global__ __launch_bounds__(256) void tap_wgrad_fold(const float *__restrict__ partial, int slices, int NT, int Cin,
-                                                      int Cout, float *__restrict__ dw, int64_t s_co, int64_t s_ci,
-                                                      int64_t s_r, int64_t s_s, int KS)
+__global__ __launch_bounds__(256) void tap_wgrad_fold(const float *__restrict__ partial, int slices, int Cin, int Cout,
+                                                      float *__restrict__ dw, int64_t s_co, int64_t s_ci,
+                                                      int64_t s_r, int64_t s_s)
 {
+    constexpr int NT = 9, KS = 3;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)NT * Cin * Cout) return;
     const int co = (int)(idx % Cout);
@@ -404,53 +480,44 @@ int wgrad_slices(long N, long Ho, long Wo, long Cin, long Cout) {
 
 extern "C" {
 
-int64_t datr_conv_s2_workspace_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t ksize) {
+int64_t datr_conv3x3s2_workspace_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
     if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return -1;
-    const int64_t Ho = (H + 1) / 2, Wo = (W + 1) / 2;       // both kernel sizes: floor((H + 2 pad - k) / 2) + 1
-    const int64_t kf = pick_ksplit(N, Ho, Wo, Cin, Cout), kd = pick_ksplit(N, Ho, Wo, Cout, Cin);
+    const int64_t Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    int64_t kf = pick_plan(N, Ho, Wo, Cin, Cout, 9).ksplit, kd = 1;
+    for (int nt = 1; nt <= 4; ++nt)          // the parity classes of the data gradient: 1, 2, 2, 4 taps
+        kd = std::max<int64_t>(kd, pick_plan(N, Ho, Wo, Cout, Cin, nt).ksplit);
+    if (getenv("DATR_TAP_PLAN")) kf = kd = 16;
     const int64_t fwd = kf > 1 ? kf * N * Ho * Wo * Cout : 0;            // split-K partial sums
     const int64_t dgr = kd > 1 ? kd * N * Ho * Wo * Cin : 0;             // per parity class (<= Ho x Wo positions)
-    const int64_t wgr = (int64_t)wgrad_slices(N, Ho, Wo, Cin, Cout) * ksize * ksize * Cin * Cout;
+    const int64_t wgr = (int64_t)wgrad_slices(N, Ho, Wo, Cin, Cout) * 9 * Cin * Cout;
     return std::max(fwd, std::max(dgr, wgr));
 }
 
-int datr_conv_s2_forward_nhwc_f32(const float *x, const float *wt, const float *scale, const float *shift,
-                                  float slope, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                                  int64_t ksize, float *y, float *workspace, int64_t workspace_floats, void *stream)
+int datr_conv3x3s2_forward_nhwc_f32(const float *x, const float *wt, const float *scale, const float *shift,
+                                    float slope, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                    float *y, float *workspace, int64_t workspace_floats, void *stream)
 {
     if (!x || !wt || !y || N < 0 || H < 1 || W < 1) return DATR_EINVAL;
-    if ((ksize != 1 && ksize != 3) || Cin % CK || Cout % BN) return DATR_EUNSUPPORTED;
-    if (N * H * W * std::max(Cin, Cout) > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    if (Cin % CK || Cout % 128) return DATR_EUNSUPPORTED;
+    if (N * H * W * std::max(Cin, Cout) > 0x1fffffffLL) return DATR_EUNSUPPORTED;        // 32-bit byte offsets
     if (N == 0) return DATR_OK;
     const int Ho = (int)((H + 1) / 2), Wo = (int)((W + 1) / 2);
     int taps[9][3], nt = 0;
-    if (ksize == 3) {
-        for (int r = 0; r < 3; ++r)
-            for (int s = 0; s < 3; ++s) { taps[nt][0] = r - 1; taps[nt][1] = s - 1; taps[nt][2] = nt; ++nt; }
-    } else {
-        taps[0][0] = taps[0][1] = taps[0][2] = 0; nt = 1;
-    }
+    for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < 3; ++s) { taps[nt][0] = r - 1; taps[nt][1] = s - 1; taps[nt][2] = nt; ++nt; }
     return launch_taps(2, x, wt, scale, shift, slope, (int)N, (int)H, (int)W, (int)Cin, (int)Cout, Ho, Wo, 1, 0, 0, Ho, Wo,
                        nt, taps, y, workspace, workspace_floats, (hipStream_t)stream);
 }
 
-int datr_conv_s2_dgrad_nhwc_f32(const float *dy, const float *wt_t, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                int64_t Cout, int64_t ksize, float *dx, float *workspace, int64_t workspace_floats,
-                                void *stream)
+int datr_conv3x3s2_dgrad_nhwc_f32(const float *dy, const float *wt_t, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                  int64_t Cout, float *dx, float *workspace, int64_t workspace_floats, void *stream)
 {
     if (!dy || !wt_t || !dx || N < 0 || H < 1 || W < 1) return DATR_EINVAL;
-    if ((ksize != 1 && ksize != 3) || Cout % CK || Cin % BN) return DATR_EUNSUPPORTED;
-    if (N * H * W * std::max(Cin, Cout) > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    if (Cout % CK || Cin % 128) return DATR_EUNSUPPORTED;
+    if (N * H * W * std::max(Cin, Cout) > 0x1fffffffLL) return DATR_EUNSUPPORTED;
     if (N == 0) return DATR_OK;
     const int Ho = (int)((H + 1) / 2), Wo = (int)((W + 1) / 2);
     hipStream_t st = (hipStream_t)stream;
-    if (ksize == 1) {
-        // only the even pixels saw the filter: the others get zeros
-        if (hipMemsetAsync(dx, 0, (size_t)N * H * W * Cin * sizeof(float), st) != hipSuccess) return DATR_ELAUNCH;
-        int taps[1][3] = {{0, 0, 0}};
-        return launch_taps(1, dy, wt_t, nullptr, nullptr, 1.f, (int)N, Ho, Wo, (int)Cout, (int)Cin, Ho, Wo, 2, 0, 0,
-                           (int)H, (int)W, 1, taps, dx, workspace, workspace_floats, st);
-    }
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             // input pixel (2 a + py, 2 b + px) was seen by output (a + dy_t, b + dx_t) through tap (r, s):
@@ -469,47 +536,35 @@ int datr_conv_s2_dgrad_nhwc_f32(const float *dy, const float *wt_t, int64_t N, i
     return DATR_OK;
 }
 
-int datr_conv_s2_wgrad_nhwc_f32(const float *x, const float *dy, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                int64_t Cout, int64_t ksize, float *dw, int64_t s_co, int64_t s_ci, int64_t s_r,
-                                int64_t s_s, float *workspace, int64_t workspace_floats, void *stream)
+int datr_conv3x3s2_wgrad_nhwc_f32(const float *x, const float *dy, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                  int64_t Cout, float *dw, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_s,
+                                  float *workspace, int64_t workspace_floats, void *stream)
 {
     if (!x || !dy || !dw || !workspace || N < 0 || H < 1 || W < 1) return DATR_EINVAL;
-    if ((ksize != 1 && ksize != 3) || Cin % WCI || Cout % WCO) return DATR_EUNSUPPORTED;
-    if (N * H * W * std::max(Cin, Cout) > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    if (Cin % WCI || Cout % WCO) return DATR_EUNSUPPORTED;
+    if (N * H * W * std::max(Cin, Cout) > 0x1fffffffLL) return DATR_EUNSUPPORTED;
     const int Ho = (int)((H + 1) / 2), Wo = (int)((W + 1) / 2);
     WgradArgs a{};
     a.x = x; a.dy = dy; a.partial = workspace;
     a.N = (int)N; a.Hin = (int)H; a.Win = (int)W; a.Cin = (int)Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = (int)Cout;
     a.tiles_x = (Wo + WTW - 1) / WTW; a.tiles_y = (Ho + WTH - 1) / WTH;
     a.slices = wgrad_slices(N, Ho, Wo, Cin, Cout);
-    a.ksize = (int)ksize;
-    const int NT = (int)(ksize * ksize);
-    if (workspace_floats < (int64_t)a.slices * NT * Cin * Cout) return DATR_EINVAL;
+    if (workspace_floats < (int64_t)a.slices * 9 * Cin * Cout) return DATR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(Cin / WCI), (unsigned)(Cout / WCO), (unsigned)a.slices);
     if (N > 0) {
-        if (ksize == 3) {
-            constexpr int PH = (WTH - 1) * 2 + 3, PW = (WTW - 1) * 2 + 3;
-            const size_t lds = (size_t)(((PH * PW * XSTR + 3) & ~3) + WTH * WTW * DSTR) * sizeof(float);
-            static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(tap_wgrad<3>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
-            if (!ok) return DATR_EUNSUPPORTED;
-            hipLaunchKernelGGL(tap_wgrad<3>, grid, dim3(kThreads), lds, st, a);
-        } else {
-            constexpr int PH = (WTH - 1) * 2 + 1, PW = (WTW - 1) * 2 + 1;
-            const size_t lds = (size_t)(((PH * PW * XSTR + 3) & ~3) + WTH * WTW * DSTR) * sizeof(float);
-            static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(tap_wgrad<1>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
-            if (!ok) return DATR_EUNSUPPORTED;
-            hipLaunchKernelGGL(tap_wgrad<1>, grid, dim3(kThreads), lds, st, a);
-        }
-    } else {
-        if (hipMemsetAsync(workspace, 0, (size_t)a.slices * NT * Cin * Cout * sizeof(float), st) != hipSuccess)
-            return DATR_ELAUNCH;
+        constexpr int PH = (WTH - 1) * 2 + 3, PW = (WTW - 1) * 2 + 3;
+        const size_t lds = (size_t)(((PH * PW * XSTR + 3) & ~3) + WTH * WTW * DSTR) * sizeof(float);
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(tap_wgrad),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+        if (!ok) return DATR_EUNSUPPORTED;
+        hipLaunchKernelGGL(tap_wgrad, grid, dim3(kThreads), lds, st, a);
+    } else if (hipMemsetAsync(workspace, 0, (size_t)a.slices * 9 * Cin * Cout * sizeof(float), st) != hipSuccess) {
+        return DATR_ELAUNCH;
     }
-    const long total = (long)NT * Cin * Cout;
-    hipLaunchKernelGGL(tap_wgrad_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, a.slices, NT,
-                       (int)Cin, (int)Cout, dw, s_co, s_ci, s_r, s_s, (int)ksize);
+    const long total = 9L * Cin * Cout;
+    hipLaunchKernelGGL(tap_wgrad_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, a.slices,
+                       (int)Cin, (int)Cout, dw, s_co, s_ci, s_r, s_s);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 

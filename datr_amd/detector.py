@@ -181,6 +181,12 @@ class DINO(nn.Module):
             y = pointwise.conv1x1(src, conv.weight, conv.bias)
             if y is not None:
                 return norm(y)
+        if conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and len(self.input_proj[lvl]) == 2:
+            # the extra pyramid level (dino.py:120-124): own stride-2 kernels, bias in the epilogue
+            from . import strided
+            y = strided.conv3x3_s2(src, conv.weight, None, conv.bias)
+            if y is not None:
+                return norm(y)
         return self.input_proj[lvl](src)
 
     def side_stream_parameters(self):
@@ -207,7 +213,7 @@ class DINO(nn.Module):
             srcs.append(self._input_proj(lvl, src))
             masks.append(mask)
         for lvl in range(len(srcs), self.num_feature_levels):
-            src = self.input_proj[lvl](features[-1].tensors if lvl == len(features) else srcs[-1])
+            src = self._input_proj(lvl, features[-1].tensors if lvl == len(features) else srcs[-1])
             mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
             poss.append(self.backbone[1](NestedTensor(src, mask, getattr(samples, "padded", None))).to(src.dtype))
             srcs.append(src)

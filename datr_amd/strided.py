@@ -1,13 +1,16 @@
-"""Stride-2 convolutions of the NHWC backbone / neck on the own MFMA kernels (csrc/conv_tap.hip).
+"""Stride-2 convolutions of the NHWC backbone / neck without the convolution library.
 
 The first bottleneck of layer2 / layer3 / layer4 carries the stage's stride on its 3x3 `conv2` and on
 the 1x1 downsample convolution beside it (/root/reference/models/dino/backbone.py:109-128 builds
 torchvision's resnet50, v1.5), and the fourth pyramid level is `input_proj[3]`, a 3x3 / stride 2
-convolution of the C5 map (/root/reference/models/dino/dino.py:120-124).  `conv_s2` runs them --
-forward with the frozen batch norm / bias and the ReLU in the epilogue, data gradient, weight
-gradient -- through `datr_conv_s2_{forward,dgrad,wgrad}_nhwc_f32`; it returns None when the tensor
-is not a channels_last float32 device tensor or the channel counts are not the kernels' (the caller
-then takes the library path).
+convolution of the C5 map (/root/reference/models/dino/dino.py:120-124).
+  * `conv3x3_s2` runs the 3x3 layers -- forward with the frozen batch norm / bias and the ReLU in the
+    epilogue, data gradient, weight gradient -- on the own MFMA kernels (csrc/conv_tap.hip,
+    `datr_conv3x3s2_{forward,dgrad,wgrad}_nhwc_f32`);
+  * `conv1x1_s2` gathers the even pixels (one strided copy of a quarter of the tensor) and takes the
+    GEMM path of every other 1x1 convolution (datr_amd.pointwise).
+Both return None when the tensor is not a channels_last float32 device tensor or the channel counts
+are not the kernels' (the caller then takes the library path).
 """
 from __future__ import annotations
 
@@ -23,32 +26,32 @@ from . import _native
 OWN_STRIDED = os.environ.get("DATR_OWN_CONV_S2", "1") != "0"
 
 
-def _workspace(x_shape, cout: int, ksize: int, device) -> torch.Tensor:
+def _workspace(x_shape, cout: int, device) -> torch.Tensor:
     N, C, H, W = x_shape
-    floats = _native.lib.datr_conv_s2_workspace_floats(N, H, W, C, cout, ksize)
+    floats = _native.lib.datr_conv3x3s2_workspace_floats(N, H, W, C, cout)
     if floats < 0:
-        raise ValueError("conv_s2: invalid shape")
+        raise ValueError("conv3x3_s2: invalid shape")
     return torch.empty(max(int(floats), 1), device=device, dtype=torch.float32)
 
 
-class _ConvS2(Function):
-    """act(conv(x, w, stride 2) * scale + shift) for a channels_last x; scale is a frozen buffer (no
-    gradient), shift may be a trainable bias (scale None); act = ReLU or identity."""
+class _Conv3x3S2(Function):
+    """act(conv3x3(x, w, stride 2, pad 1) * scale + shift) for a channels_last x; scale is a frozen
+    buffer (no gradient), shift may be a trainable bias (scale None); act = ReLU or identity."""
 
     @staticmethod
     def forward(ctx, x, w, scale, shift, relu):
         N, C, H, W = x.shape
-        co, _, k, _ = w.shape
+        co = w.shape[0]
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
-        wt = w.permute(2, 3, 1, 0).contiguous()                      # [k, k, Cin, Cout]
+        wt = w.permute(2, 3, 1, 0).contiguous()                      # [3, 3, Cin, Cout]
         y = torch.empty((N, co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-        ws = _workspace(x.shape, co, k, x.device)
+        ws = _workspace(x.shape, co, x.device)
         with torch.cuda.device(x.device):
-            rc = _native.lib.datr_conv_s2_forward_nhwc_f32(
+            rc = _native.lib.datr_conv3x3s2_forward_nhwc_f32(
                 x.data_ptr(), wt.data_ptr(), 0 if scale is None else scale.data_ptr(),
-                0 if shift is None else shift.data_ptr(), 0.0 if relu else 1.0, N, H, W, C, co, k,
+                0 if shift is None else shift.data_ptr(), 0.0 if relu else 1.0, N, H, W, C, co,
                 y.data_ptr(), ws.data_ptr(), ws.numel(), _native.current_stream_ptr(x.device))
-        _native.check(rc, "conv_s2_forward")
+        _native.check(rc, "conv3x3s2_forward")
         ctx.save_for_backward(x, w, y if relu else None, scale)
         ctx.relu, ctx.bias_grad = bool(relu), scale is None and shift is not None
         return y
@@ -58,7 +61,7 @@ class _ConvS2(Function):
     def backward(ctx, dy):
         x, w, y, scale = ctx.saved_tensors
         N, C, H, W = x.shape
-        co, _, k, _ = w.shape
+        co = w.shape[0]
         need = ctx.needs_input_grad
         dy = dy.contiguous(memory_format=torch.channels_last)
         stream = _native.current_stream_ptr(dy.device)
@@ -75,37 +78,49 @@ class _ConvS2(Function):
         else:
             dz = dy
         dx = dw = db = None
-        ws = _workspace(x.shape, co, k, x.device)
+        ws = _workspace(x.shape, co, x.device)
         with torch.cuda.device(dy.device):
             if need[0]:
-                wt_t = w.permute(2, 3, 0, 1).contiguous()             # [k, k, Cout, Cin]
+                wt_t = w.permute(2, 3, 0, 1).contiguous()             # [3, 3, Cout, Cin]
                 dx = torch.empty_like(x, memory_format=torch.channels_last)
-                rc = _native.lib.datr_conv_s2_dgrad_nhwc_f32(dz.data_ptr(), wt_t.data_ptr(), N, H, W, C, co, k,
-                                                             dx.data_ptr(), ws.data_ptr(), ws.numel(), stream)
-                _native.check(rc, "conv_s2_dgrad")
+                rc = _native.lib.datr_conv3x3s2_dgrad_nhwc_f32(dz.data_ptr(), wt_t.data_ptr(), N, H, W, C, co,
+                                                               dx.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                _native.check(rc, "conv3x3s2_dgrad")
             if need[1]:
                 dw = torch.empty_like(w)                                 # preserves the strides
                 s = dw.stride()
-                rc = _native.lib.datr_conv_s2_wgrad_nhwc_f32(x.data_ptr(), dz.data_ptr(), N, H, W, C, co, k,
-                                                             dw.data_ptr(), s[0], s[1], s[2], s[3],
-                                                             ws.data_ptr(), ws.numel(), stream)
-                _native.check(rc, "conv_s2_wgrad")
+                rc = _native.lib.datr_conv3x3s2_wgrad_nhwc_f32(x.data_ptr(), dz.data_ptr(), N, H, W, C, co,
+                                                               dw.data_ptr(), s[0], s[1], s[2], s[3],
+                                                               ws.data_ptr(), ws.numel(), stream)
+                _native.check(rc, "conv3x3s2_wgrad")
         if ctx.bias_grad and need[3]:
             from .fused import column_sums
             db = column_sums(dz.permute(0, 2, 3, 1).reshape(-1, co))
         return dx, dw, None, db, None
 
 
-def conv_s2(x: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: bool = False):
-    """act(F.conv2d(x, w, stride=2, padding=k // 2) * scale + shift) on the own kernels, k = 1 or 3; None
-    when they do not apply."""
+def conv3x3_s2(x: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: bool = False):
+    """act(F.conv2d(x, w, stride=2, padding=1) * scale + shift) on the own kernels; None when they do not
+    apply."""
     if not (OWN_STRIDED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and w.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()):
         return None
     co, ci, kh, kw = w.shape
-    if kh != kw or kh not in (1, 3) or ci != x.shape[1] or ci % 128 or co % 128:
+    if (kh, kw) != (3, 3) or ci != x.shape[1] or ci % 128 or co % 128:
         return None
     if scale is not None and scale.requires_grad:
         return None
-    return _ConvS2.apply(x, w, None if scale is None else scale.contiguous(),
-                         None if shift is None else shift.contiguous(), relu)
+    return _Conv3x3S2.apply(x, w, None if scale is None else scale.contiguous(),
+                            None if shift is None else shift.contiguous(), relu)
+
+
+def conv1x1_s2(x: torch.Tensor, weight: torch.Tensor, bias=None, relu: bool = False):
+    """act(F.conv2d(x, weight[Cout, Cin(, 1, 1)], bias, stride=2)): the even pixels gathered into a dense
+    channels_last tensor (autograd scatters the gradient back), then the 1x1 GEMM path; None when that
+    path does not apply."""
+    from . import pointwise
+    if not (OWN_STRIDED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    xs = x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
+    return pointwise.conv1x1(xs, weight, bias, relu)

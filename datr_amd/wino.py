@@ -20,7 +20,7 @@ OWN_BACKBONE_3X3 = os.environ.get("DATR_OWN_CONV3X3", "1") != "0"
 # frozen BN + ReLU, own vs library + fused affine pass): 64 ch 179 vs 216 us, 128 ch 178 vs 191 us
 # (fwd+bwd 510 vs 545); 256 ch 197 vs 184 us, 512 ch 194 vs 176 us -- the 50x84 / 25x42 maps fill
 # only 1.5 / 0.75 rounds of 16x16-pixel workgroups, so layer3 / layer4 stay on the library.
-OWN_BACKBONE_3X3_MAX_CH = int(os.environ.get("DATR_OWN_CONV3X3_MAX_CH", "128"))
+OWN_BACKBONE_3X3_MAX_CH = int(os.environ.get("DATR_OWN_CONV3X3_MAX_CH", "512"))
 
 
 def _nhwc(x: torch.Tensor) -> torch.Tensor:

@@ -255,32 +255,30 @@ int datr_conv3x3_cout1_backward_f32(const datr_c1_level *levels, int64_t nlevels
                                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * Stride-2 convolutions on NHWC tensors (csrc/conv_tap.hip): the 3x3 / stride 2 / pad 1 `conv2` and
- * the 1x1 / stride 2 downsample convolution of the first bottleneck of layer2-4
- * (/root/reference/models/dino/backbone.py:109-128: torchvision resnet50) and `input_proj[3]`
- * (/root/reference/models/dino/dino.py:120-124: Conv2d(2048, 256, 3, stride 2, padding 1)); replaces
- * `nn.Conv2d.forward` and the two halves of autograd's convolution backward for those layers.
- * ksize = 3 (pad 1) or 1 (pad 0); x: [N, H, W, Cin]; y / dy: [N, (H + 1) / 2, (W + 1) / 2, Cout].
+ * 3x3 / stride 2 / pad 1 convolutions on NHWC tensors (csrc/conv_tap.hip): `conv2` of the first
+ * bottleneck of layer2-4 (/root/reference/models/dino/backbone.py:109-128: torchvision resnet50) and
+ * `input_proj[3]` (/root/reference/models/dino/dino.py:120-124: Conv2d(2048, 256, 3, stride 2,
+ * padding 1)); replaces `nn.Conv2d.forward` and the two halves of autograd's convolution backward for
+ * those layers.  x: [N, H, W, Cin]; y / dy: [N, (H + 1) / 2, (W + 1) / 2, Cout].
  *   forward  y = act(conv(x) * scale + shift); scale / shift [Cout] or NULL; act = LeakyReLU(slope)
- *            (slope 0: ReLU, 1: none).  wt: [ksize^2][Cin][Cout] = W.permute(2, 3, 1, 0).
+ *            (slope 0: ReLU, 1: none).  wt: [9][Cin][Cout] = W.permute(2, 3, 1, 0).
  *            Cin % 16 == 0, Cout % 128 == 0.
- *   dgrad    dx = conv_transpose(dy); wt_t: [ksize^2][Cout][Cin] = W.permute(2, 3, 0, 1).
+ *   dgrad    dx = conv_transpose(dy); wt_t: [9][Cout][Cin] = W.permute(2, 3, 0, 1).
  *            Cout % 16 == 0, Cin % 128 == 0.  dx is overwritten.
  *   wgrad    dw[co * s_co + ci * s_ci + r * s_r + s * s_s] = sum x dy (overwritten).
  *            Cin % 32 == 0, Cout % 128 == 0.
- * `workspace`: datr_conv_s2_workspace_floats(...) floats of scratch (split-K partial sums, added in a
- * fixed order: results are bitwise reproducible). */
-int64_t datr_conv_s2_workspace_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t ksize);
-int datr_conv_s2_forward_nhwc_f32(const float *x, const float *wt, const float *scale, const float *shift,
-                                  float slope, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                                  int64_t ksize, float *y, float *workspace, int64_t workspace_floats,
-                                  void *stream);
-int datr_conv_s2_dgrad_nhwc_f32(const float *dy, const float *wt_t, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                int64_t Cout, int64_t ksize, float *dx, float *workspace,
-                                int64_t workspace_floats, void *stream);
-int datr_conv_s2_wgrad_nhwc_f32(const float *x, const float *dy, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                int64_t Cout, int64_t ksize, float *dw, int64_t s_co, int64_t s_ci, int64_t s_r,
-                                int64_t s_s, float *workspace, int64_t workspace_floats, void *stream);
+ * `workspace`: datr_conv3x3s2_workspace_floats(...) floats of scratch (split-K partial sums, added in
+ * a fixed order: results are bitwise reproducible). */
+int64_t datr_conv3x3s2_workspace_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout);
+int datr_conv3x3s2_forward_nhwc_f32(const float *x, const float *wt, const float *scale, const float *shift,
+                                    float slope, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                    float *y, float *workspace, int64_t workspace_floats, void *stream);
+int datr_conv3x3s2_dgrad_nhwc_f32(const float *dy, const float *wt_t, int64_t N, int64_t H, int64_t W,
+                                  int64_t Cin, int64_t Cout, float *dx, float *workspace,
+                                  int64_t workspace_floats, void *stream);
+int datr_conv3x3s2_wgrad_nhwc_f32(const float *x, const float *dy, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                  int64_t Cout, float *dw, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_s,
+                                  float *workspace, int64_t workspace_floats, void *stream);
 
 /* Weight gradient of the same convolutions in the Winograd domain (csrc/wino_wgrad.hip):
  * dW = G^T [ sum over 2x2 tiles (A dY A^T) o (B^T x B) ] G, summed over all levels (they share the

@@ -35,7 +35,7 @@ CASES = [
 
 @pytest.mark.parametrize("N,ci,co,H,W,k,bn,relu,bias", CASES)
 def test_conv_s2_matches_float64_autograd(N, ci, co, H, W, k, bn, relu, bias):
-    from datr_amd.strided import conv_s2
+    from datr_amd.strided import conv1x1_s2, conv3x3_s2
     g = torch.Generator().manual_seed(H * 131 + W)
     dev = torch.device("cuda:0")
     x = torch.randn(N, ci, H, W, generator=g)
@@ -53,7 +53,11 @@ def test_conv_s2_matches_float64_autograd(N, ci, co, H, W, k, bn, relu, bias):
     xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     wg = w.to(dev).requires_grad_(True)
     sg = None if shift is None else shift.to(dev).requires_grad_(bias)
-    y = conv_s2(xg, wg, None if scale is None else scale.to(dev), sg, relu)
+    if k == 3:
+        y = conv3x3_s2(xg, wg, None if scale is None else scale.to(dev), sg, relu)
+    else:
+        # the downsample path: frozen scale folded into the weight, shift as the GEMM's bias
+        y = conv1x1_s2(xg, wg * scale.to(dev).view(-1, 1, 1, 1), sg, relu)
     assert y is not None and y.shape == yd.shape
     assert y.is_contiguous(memory_format=torch.channels_last)
     y.backward(gy.to(dev))
@@ -73,7 +77,7 @@ def test_conv_s2_matches_float64_autograd(N, ci, co, H, W, k, bn, relu, bias):
 
 
 def test_conv_s2_is_bitwise_reproducible():
-    from datr_amd.strided import conv_s2
+    from datr_amd.strided import conv1x1_s2, conv3x3_s2
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
     x = torch.randn(4, 512, 25, 42, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -82,7 +86,7 @@ def test_conv_s2_is_bitwise_reproducible():
     outs = []
     for _ in range(2):
         xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-        y = conv_s2(xg, wg)
+        y = conv3x3_s2(xg, wg)
         y.backward(gy)
         outs.append((y.detach().clone(), xg.grad.clone(), wg.grad.clone()))
     for a, b in zip(*outs):
