@@ -228,8 +228,11 @@ class _StageOutputs(nn.ModuleDict):
             if (name == "conv1" and i + 2 < len(items)
                     and isinstance(items[i + 1][1], FrozenBatchNorm2d)
                     and isinstance(items[i + 2][1], nn.ReLU)):
-                # stem: conv -> frozen BN -> ReLU as conv + one fused pass
-                x = frozen_bn_act(child(x), *items[i + 1][1].scale_shift(), relu=True)
+                # stem: conv -> frozen BN -> ReLU in one launch (csrc/stem.hip) when the stem is
+                # frozen, else the library convolution + one fused pass
+                y = strided.stem_conv_bn_relu(x, child.weight, *items[i + 1][1].scale_shift()) \
+                    if (child.bias is None and child.stride == (2, 2) and child.padding == (3, 3)) else None
+                x = y if y is not None else frozen_bn_act(child(x), *items[i + 1][1].scale_shift(), relu=True)
                 i += 3
                 continue
             x = child(x)

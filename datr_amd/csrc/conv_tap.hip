@@ -48,18 +48,23 @@ constexpr int CK = 16;                         // input channels per chunk
 constexpr int PSTR = 20;                       // patch pixel stride in floats (16 + 4 pad)
 constexpr int kMaxTaps = 9;
 
-struct TapArgs {
-    const float *x, *wt, *scale, *shift;
-    float *y;                                   // output tensor, or the partial buffer when ksplit > 1
-    int Hin, Win, Cin, Cout;
+struct TapClass {                               // one output class of a launch (forward: one; data gradient: four parities)
     int Hidx, Widx;                             // positions computed
-    int OS, OOy, OOx, Hout, Wout;               // where position (oy, ox) lands in the output tensor
-    int tiles_x, tiles_y, ksplit;
+    int OOy, OOx;                               // position (oy, ox) lands at (oy OS + OOy, ox OS + OOx)
+    int tiles_x, tiles_y, tile0;                // its tiles are blockIdx.x in [tile0, tile0 + N tiles_x tiles_y)
     int mindy, mindx, PH, PW, PW2;              // patch geometry (PW2 = columns per parity plane)
     int ntaps;
     int toff[kMaxTaps];                         // LDS float offset of a tap relative to a lane's base
     int widx[kMaxTaps];                         // weight matrix of the tap
+};
+struct TapArgs {
+    const float *x, *wt, *scale, *shift;
+    float *y;                                   // output tensor, or the partial buffer when ksplit > 1
+    int Hin, Win, Cin, Cout;
+    int OS, Hout, Wout;
+    int ksplit, ncls, slab0_floats;             // slabs start behind the largest class's patch
     float slope;
+    TapClass cls[4];
 };
 
 constexpr int kSlabs = 4;                      // weight-slab ring: two (tap, chunk) steps in flight
@@ -87,14 +92,17 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) float lds_f;
     typedef __attribute__((address_space(3))) f4 lds_f4;
-    const unsigned slab0 = (unsigned)((a.PH * planes * a.PW2 * PSTR + 3) & ~3) * 4u;     // bytes
+    const unsigned slab0 = (unsigned)a.slab0_floats * 4u;                               // bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
-    int b = blockIdx.x;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    int ci_ = a.ncls - 1;
+    while (ci_ > 0 && (int)blockIdx.x < a.cls[ci_].tile0) --ci_;
+    const TapClass &c = a.cls[ci_];
+    int b = (int)blockIdx.x - c.tile0;
+    const int tx = b % c.tiles_x; b /= c.tiles_x;
+    const int ty = b % c.tiles_y; b /= c.tiles_y;
     const int n = b;
     constexpr int NJ = BNT / 64;                // 32-column accumulator tiles per wave
     constexpr int kSlabInstr = BNT / 64;        // LDS-DMA instructions per wave and slab (1 KB each)
@@ -129,8 +137,8 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
     // (pixels outside the image or past the patch get an out-of-range offset and read zeros: the
     // SAME number of loads for every thread and chunk, so the waits below can count them), one chunk
     // ahead into registers, and writes them to LDS when the chunk is switched.
-    const int PH = a.PH, PW = a.PW, PW2 = a.PW2;
-    const int gy0 = oy0 * IS + a.mindy, gx0 = ox0 * IS + a.mindx;
+    const int PH = c.PH, PW = c.PW, PW2 = c.PW2;
+    const int gy0 = oy0 * IS + c.mindy, gx0 = ox0 * IS + c.mindx;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x + (size_t)n * a.Hin * a.Win * Cin), 0, a.Hin * a.Win * Cin * 4, 0x00020000);
     int poff[kPatchLoads], pat[kPatchLoads];
@@ -169,12 +177,12 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
 
     const int nchunks = Cin / CK;
     const int ch0 = (int)((long)blockIdx.z * nchunks / a.ksplit), ch1 = (int)((long)(blockIdx.z + 1) * nchunks / a.ksplit);
-    const int ntaps = a.ntaps;
+    const int ntaps = c.ntaps;
     const int nsteps = (ch1 - ch0) * ntaps;
     // step s = (chunk ch0 + s / ntaps, tap s % ntaps); its slab lives in ring slot s % kSlabs
     auto issue_slab = [&](int s) {
-        const int c = s / ntaps, t = s - c * ntaps;
-        dma_w(a.widx[t], (ch0 + c) * CK, s % kSlabs);
+        const int cc = s / ntaps, t = s - cc * ntaps;
+        dma_w(c.widx[t], (ch0 + cc) * CK, s % kSlabs);
     };
     fetch_patch(ch0 * CK);
     if (nsteps > 0) issue_slab(0);
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (t == 0 && ch + 1 < ch1) fetch_patch((ch + 1) * CK);
             const int buf = s % kSlabs;
-            const int toff = a.toff[t];
+            const int toff = c.toff[t];
 #pragma unroll
             for (int grp = 0; grp < 2; ++grp) {          // two 8-channel groups of the chunk
                 f4 av[2];
@@ -231,9 +239,9 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
     if (!raw) {
 #pragma unroll
         for (int jn = 0; jn < NJ; ++jn) {
-            const int c = co0 + wn * (BNT / 2) + jn * 32 + l31;
-            if (a.scale) sc[jn] = a.scale[c];
-            if (a.shift) sh[jn] = a.shift[c];
+            const int ch = co0 + wn * (BNT / 2) + jn * 32 + l31;
+            if (a.scale) sc[jn] = a.scale[ch];
+            if (a.shift) sh[jn] = a.shift[ch];
         }
     }
     const float slope = raw ? 1.f : a.slope;
@@ -244,12 +252,12 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
             const int prow = (e & 3) + 8 * (e >> 2) + 4 * lhi;          // position within the 32-block
             const int py = wm * 4 + i * 2 + (prow >> 4), px = prow & 15;
             const int oy = oy0 + py, ox = ox0 + px;
-            if (oy < a.Hidx && ox < a.Widx) {
+            if (oy < c.Hidx && ox < c.Widx) {
                 float *yb;
-                if (raw)
-                    yb = a.y + ((((size_t)blockIdx.z * gridDim.x / (a.tiles_x * a.tiles_y) + n) * a.Hidx + oy) * a.Widx + ox) * Cout;
+                if (raw)         // (single-class launches only)
+                    yb = a.y + ((((size_t)blockIdx.z * gridDim.x / (c.tiles_x * c.tiles_y) + n) * c.Hidx + oy) * c.Widx + ox) * Cout;
                 else
-                    yb = a.y + (((size_t)n * a.Hout + oy * a.OS + a.OOy) * a.Wout + ox * a.OS + a.OOx) * Cout;
+                    yb = a.y + (((size_t)n * a.Hout + oy * a.OS + c.OOy) * a.Wout + ox * a.OS + c.OOx) * Cout;
                 yb += co0 + wn * (BNT / 2) + l31;
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn) {
@@ -297,55 +305,65 @@ __global__ __launch_bounds__(256) void tap_fold(const float *__restrict__ partia
 // in two (672 workgroups) for layer3.0.conv2; 401 -> 279 us with K split in four for layer4.0.conv2
 // (192 tiles); splitting further, or 64-channel workgroups instead, was slower (tools/probes/
 // conv_tap_plans.sh).  The partial sums are added in a fixed order (tap_fold).
-struct TapPlan { int bn, ksplit; };
-TapPlan pick_plan(long N, long Hidx, long Widx, long Cin, long Cout, int ntaps) {
-    (void)ntaps;
-    const long wgs = N * ((Widx + TW - 1) / TW) * ((Hidx + TH - 1) / TH) * (Cout / 128);
-    const long nchunks = Cin / CK;
+int pick_ksplit(long wgs, long nchunks) {
     if (const char *f = getenv("DATR_TAP_PLAN")) {          // development: "128,ksplit"
         int bn = 0, ks = 0;
-        if (sscanf(f, "%d,%d", &bn, &ks) == 2 && bn == 128 && ks >= 1 && ks <= 16 && ks <= nchunks) return TapPlan{bn, ks};
+        if (sscanf(f, "%d,%d", &bn, &ks) == 2 && bn == 128 && ks >= 1 && ks <= 16 && ks <= nchunks) return ks;
     }
     int ks = 1;
     while (wgs * ks < 512 && ks * 2 <= nchunks / 2 && ks < 16) ks *= 2;
-    return TapPlan{128, ks};
+    return ks;
 }
 
+// One launch over `ncls` output classes that share input, weights and epilogue.
+struct TapClassSpec { int Hidx, Widx, OOy, OOx, ntaps; int taps[kMaxTaps][3]; };
+
 int launch_taps(int IS, const float *x, const float *wt, const float *scale, const float *shift, float slope,
-                int N, int Hin, int Win, int Cin, int Cout, int Hidx, int Widx, int OS, int OOy, int OOx, int Hout,
-                int Wout, int ntaps, const int (*taps)[3], float *y, float *partial, long partial_floats,
-                hipStream_t st)
+                int N, int Hin, int Win, int Cin, int Cout, int OS, int Hout, int Wout, int ncls,
+                const TapClassSpec *specs, float *y, float *partial, long partial_floats, hipStream_t st)
 {
-    if (Hidx <= 0 || Widx <= 0) return DATR_OK;
     TapArgs a{};
     a.x = x; a.wt = wt; a.scale = scale; a.shift = shift; a.slope = slope;
-    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.Hidx = Hidx; a.Widx = Widx;
-    a.OS = OS; a.OOy = OOy; a.OOx = OOx; a.Hout = Hout; a.Wout = Wout;
-    a.tiles_x = (Widx + TW - 1) / TW; a.tiles_y = (Hidx + TH - 1) / TH;
-    int mindy = 1 << 20, mindx = 1 << 20, maxdy = -(1 << 20), maxdx = -(1 << 20);
-    for (int t = 0; t < ntaps; ++t) {
-        mindy = std::min(mindy, taps[t][0]); maxdy = std::max(maxdy, taps[t][0]);
-        mindx = std::min(mindx, taps[t][1]); maxdx = std::max(maxdx, taps[t][1]);
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout;
+    a.OS = OS; a.Hout = Hout; a.Wout = Wout;
+    int tiles = 0, patch_floats = 0, nc = 0;
+    for (int k = 0; k < ncls; ++k) {
+        const TapClassSpec &sp = specs[k];
+        if (sp.Hidx <= 0 || sp.Widx <= 0 || sp.ntaps <= 0) continue;
+        TapClass &c = a.cls[nc++];
+        c.Hidx = sp.Hidx; c.Widx = sp.Widx; c.OOy = sp.OOy; c.OOx = sp.OOx;
+        c.tiles_x = (sp.Widx + TW - 1) / TW; c.tiles_y = (sp.Hidx + TH - 1) / TH;
+        c.tile0 = tiles;
+        tiles += N * c.tiles_x * c.tiles_y;
+        int mindy = 1 << 20, mindx = 1 << 20, maxdy = -(1 << 20), maxdx = -(1 << 20);
+        for (int t = 0; t < sp.ntaps; ++t) {
+            mindy = std::min(mindy, sp.taps[t][0]); maxdy = std::max(maxdy, sp.taps[t][0]);
+            mindx = std::min(mindx, sp.taps[t][1]); maxdx = std::max(maxdx, sp.taps[t][1]);
+        }
+        c.mindy = mindy; c.mindx = mindx;
+        c.PH = (TH - 1) * IS + (maxdy - mindy) + 1;
+        c.PW = (TW - 1) * IS + (maxdx - mindx) + 1;
+        c.PW2 = IS == 2 ? (c.PW + 1) / 2 : c.PW;
+        c.ntaps = sp.ntaps;
+        for (int t = 0; t < sp.ntaps; ++t) {
+            const int ddy = sp.taps[t][0] - mindy, ddx = sp.taps[t][1] - mindx;
+            c.toff[t] = IS == 2 ? ((ddy * 2 + (ddx & 1)) * c.PW2 + (ddx >> 1)) * PSTR : (ddy * c.PW2 + ddx) * PSTR;
+            c.widx[t] = sp.taps[t][2];
+        }
+        if (c.PH * c.PW * 4 > kPatchLoads * kThreads) return DATR_EUNSUPPORTED;
+        patch_floats = std::max(patch_floats, (c.PH * IS * c.PW2 * PSTR + 3) & ~3);
     }
-    a.mindy = mindy; a.mindx = mindx;
-    a.PH = (TH - 1) * IS + (maxdy - mindy) + 1;
-    a.PW = (TW - 1) * IS + (maxdx - mindx) + 1;
-    a.PW2 = IS == 2 ? (a.PW + 1) / 2 : a.PW;
-    a.ntaps = ntaps;
-    for (int t = 0; t < ntaps; ++t) {
-        const int ddy = taps[t][0] - mindy, ddx = taps[t][1] - mindx;
-        a.toff[t] = IS == 2 ? ((ddy * 2 + (ddx & 1)) * a.PW2 + (ddx >> 1)) * PSTR : (ddy * a.PW2 + ddx) * PSTR;
-        a.widx[t] = taps[t][2];
-    }
-    const TapPlan plan = pick_plan(N, Hidx, Widx, Cin, Cout, ntaps);
-    int ksplit = plan.ksplit;
-    const int bn = plan.bn;
-    const long per_split = (long)N * Hidx * Widx * Cout;
+    if (nc == 0 || N == 0) return DATR_OK;
+    a.ncls = nc;
+    a.slab0_floats = patch_floats;
+    // K is split for single-class launches only (the partial buffer is laid out for one class)
+    int ksplit = nc == 1 ? pick_ksplit((long)tiles * (Cout / 128), Cin / CK) : 1;
+    const long per_split = (long)N * a.cls[0].Hidx * a.cls[0].Widx * Cout;
     if (ksplit > 1 && (!partial || partial_floats < per_split * ksplit)) ksplit = 1;
     a.ksplit = ksplit;
     a.y = ksplit > 1 ? partial : y;
-    const size_t lds = (size_t)(((a.PH * IS * a.PW2 * PSTR + 3) & ~3) + kSlabs * CK * bn) * sizeof(float);
-    dim3 grid((unsigned)(N * a.tiles_x * a.tiles_y), (unsigned)(Cout / bn), (unsigned)ksplit);
+    const size_t lds = (size_t)(patch_floats + kSlabs * CK * 128) * sizeof(float);
+    dim3 grid((unsigned)tiles, (unsigned)(Cout / 128), (unsigned)ksplit);
     auto go = [&](auto kernel) {
         static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
@@ -356,9 +374,10 @@ int launch_taps(int IS, const float *x, const float *wt, const float *scale, con
     const bool launched = IS == 2 ? go(tap_conv<2, 128>) : go(tap_conv<1, 128>);
     if (!launched) return DATR_EUNSUPPORTED;
     if (ksplit > 1) {
+        const TapClass &c = a.cls[0];
         const long n4 = per_split / 4;
         hipLaunchKernelGGL(tap_fold, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, partial, ksplit, per_split,
-                           scale, shift, slope, N, Hidx, Widx, Cout, OS, OOy, OOx, Hout, Wout, y);
+                           scale, shift, slope, N, c.Hidx, c.Widx, Cout, OS, c.OOy, c.OOx, Hout, Wout, y);
     }
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
@@ -396,39 +415,68 @@ __global__ __launch_bounds__(kThreads, 2) void tap_wgrad(const WgradArgs a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    // A tile's input patch and dY block travel global -> registers (one tile AHEAD, while the current
+    // tile is multiplied) -> LDS.  Buffer loads: pixels outside the image / map get an out-of-range
+    // offset and read zeros, so every thread issues the same loads for every tile.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int kXLoads = (PH * PW * 8 + kThreads - 1) / kThreads, kDLoads = WTH * WTW * 32 / kThreads;
+    f4 rx[kXLoads], rd[kDLoads];
     const int ntiles = a.N * a.tiles_y * a.tiles_x;
-    for (int tile = slice; tile < ntiles; tile += a.slices) {
+    auto fetch = [&](int tile) {
         int b = tile;
         const int tx = b % a.tiles_x; b /= a.tiles_x;
         const int ty = b % a.tiles_y; b /= a.tiles_y;
         const int n = b;
         const int oy0 = ty * WTH, ox0 = tx * WTW;
         const int gy0 = oy0 * 2 - pad, gx0 = ox0 * 2 - pad;
-        const float *Xn = a.x + (size_t)n * a.Hin * a.Win * Cin + ci0;
-        const float *Dn = a.dy + (size_t)n * a.Ho * a.Wo * Cout + co0;
-        __syncthreads();                                // the previous tile's readers are done
-        for (int f = tid; f < PH * PW * 8; f += kThreads) {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.x + (size_t)n * a.Hin * a.Win * Cin), 0, a.Hin * a.Win * Cin * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.dy + (size_t)n * a.Ho * a.Wo * Cout), 0, a.Ho * a.Wo * Cout * 4, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < kXLoads; ++u) {
+            const int f = tid + u * kThreads;
             const int pix = f >> 3, q = f & 7;
             const int pr = pix / PW, pc = pix - pr * PW;
             const int yy = gy0 + pr, xx = gx0 + pc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win)
-                v = *reinterpret_cast<const float4 *>(Xn + ((size_t)yy * a.Win + xx) * Cin + q * 4);
-            float2 *d = reinterpret_cast<float2 *>(&xs[pix * XSTR + q * 4]);      // 136-B pixels: 8-B aligned
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+            const bool in = f < PH * PW * 8 && yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win;
+            const int off = in ? ((yy * a.Win + xx) * Cin + ci0 + q * 4) * 4 : (int)0x80000000;
+            rx[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
         }
-        for (int f = tid; f < WTH * WTW * 32; f += kThreads) {
+#pragma unroll
+        for (int u = 0; u < kDLoads; ++u) {
+            const int f = tid + u * kThreads;
             const int pos = f >> 5, q = f & 31;
             const int oy = oy0 + (pos >> 4), ox = ox0 + (pos & 15);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < a.Ho && ox < a.Wo)
-                v = *reinterpret_cast<const float4 *>(Dn + ((size_t)oy * a.Wo + ox) * Cout + q * 4);
-            *reinterpret_cast<float4 *>(&ds[pos * DSTR + q * 4]) = v;
+            const bool in = oy < a.Ho && ox < a.Wo;
+            const int off = in ? ((oy * a.Wo + ox) * Cout + co0 + q * 4) * 4 : (int)0x80000000;
+            rd[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(dr, off, 0, 0));
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < kXLoads; ++u) {
+            const int f = tid + u * kThreads;
+            if (f < PH * PW * 8) {
+                float2 *d = reinterpret_cast<float2 *>(&xs[(f >> 3) * XSTR + (f & 7) * 4]);      // 136-B pixels: 8-B aligned
+                d[0] = make_float2(rx[u].x, rx[u].y);
+                d[1] = make_float2(rx[u].z, rx[u].w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kDLoads; ++u) {
+            const int f = tid + u * kThreads;
+            *reinterpret_cast<f4 *>(&ds[(f >> 5) * DSTR + (f & 31) * 4]) = rd[u];
+        }
+    };
+    if (slice < ntiles) fetch(slice);
+    for (int tile = slice; tile < ntiles; tile += a.slices) {
+        __syncthreads();                                // the previous tile's readers are done
+        stash();
         __syncthreads();
+        if (tile + a.slices < ntiles) fetch(tile + a.slices);
         // 32 k-steps: positions (py, pxl) and (py, pxl + 8)
-#pragma unroll 2
+#pragma unroll 1
         for (int s = 0; s < 32; ++s) {
             const int py = s >> 3, px = (s & 7) + 8 * lhi;
             const float bv = ds[(py * 16 + px) * DSTR + wave * 32 + l31];
@@ -483,14 +531,12 @@ extern "C" {
 int64_t datr_conv3x3s2_workspace_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
     if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return -1;
     const int64_t Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    int64_t kf = pick_plan(N, Ho, Wo, Cin, Cout, 9).ksplit, kd = 1;
-    for (int nt = 1; nt <= 4; ++nt)          // the parity classes of the data gradient: 1, 2, 2, 4 taps
-        kd = std::max<int64_t>(kd, pick_plan(N, Ho, Wo, Cout, Cin, nt).ksplit);
-    if (getenv("DATR_TAP_PLAN")) kf = kd = 16;
-    const int64_t fwd = kf > 1 ? kf * N * Ho * Wo * Cout : 0;            // split-K partial sums
-    const int64_t dgr = kd > 1 ? kd * N * Ho * Wo * Cin : 0;             // per parity class (<= Ho x Wo positions)
+    const int64_t tiles = N * ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH);
+    int64_t kf = pick_ksplit(tiles * (Cout / 128), Cin / CK);
+    if (getenv("DATR_TAP_PLAN")) kf = 16;
+    const int64_t fwd = kf > 1 ? kf * N * Ho * Wo * Cout : 0;            // split-K partial sums of the forward
     const int64_t wgr = (int64_t)wgrad_slices(N, Ho, Wo, Cin, Cout) * 9 * Cin * Cout;
-    return std::max(fwd, std::max(dgr, wgr));
+    return std::max(fwd, wgr);
 }
 
 int datr_conv3x3s2_forward_nhwc_f32(const float *x, const float *wt, const float *scale, const float *shift,
@@ -500,13 +546,16 @@ int datr_conv3x3s2_forward_nhwc_f32(const float *x, const float *wt, const float
     if (!x || !wt || !y || N < 0 || H < 1 || W < 1) return DATR_EINVAL;
     if (Cin % CK || Cout % 128) return DATR_EUNSUPPORTED;
     if (N * H * W * std::max(Cin, Cout) > 0x1fffffffLL) return DATR_EUNSUPPORTED;        // 32-bit byte offsets
-    if (N == 0) return DATR_OK;
     const int Ho = (int)((H + 1) / 2), Wo = (int)((W + 1) / 2);
-    int taps[9][3], nt = 0;
+    TapClassSpec sp{};
+    sp.Hidx = Ho; sp.Widx = Wo; sp.OOy = sp.OOx = 0;
     for (int r = 0; r < 3; ++r)
-        for (int s = 0; s < 3; ++s) { taps[nt][0] = r - 1; taps[nt][1] = s - 1; taps[nt][2] = nt; ++nt; }
-    return launch_taps(2, x, wt, scale, shift, slope, (int)N, (int)H, (int)W, (int)Cin, (int)Cout, Ho, Wo, 1, 0, 0, Ho, Wo,
-                       nt, taps, y, workspace, workspace_floats, (hipStream_t)stream);
+        for (int s = 0; s < 3; ++s) {
+            sp.taps[sp.ntaps][0] = r - 1; sp.taps[sp.ntaps][1] = s - 1; sp.taps[sp.ntaps][2] = r * 3 + s;
+            ++sp.ntaps;
+        }
+    return launch_taps(2, x, wt, scale, shift, slope, (int)N, (int)H, (int)W, (int)Cin, (int)Cout, 1, Ho, Wo, 1, &sp, y,
+                       workspace, workspace_floats, (hipStream_t)stream);
 }
 
 int datr_conv3x3s2_dgrad_nhwc_f32(const float *dy, const float *wt_t, int64_t N, int64_t H, int64_t W, int64_t Cin,
@@ -515,25 +564,26 @@ int datr_conv3x3s2_dgrad_nhwc_f32(const float *dy, const float *wt_t, int64_t N,
     if (!dy || !wt_t || !dx || N < 0 || H < 1 || W < 1) return DATR_EINVAL;
     if (Cout % CK || Cin % 128) return DATR_EUNSUPPORTED;
     if (N * H * W * std::max(Cin, Cout) > 0x1fffffffLL) return DATR_EUNSUPPORTED;
-    if (N == 0) return DATR_OK;
     const int Ho = (int)((H + 1) / 2), Wo = (int)((W + 1) / 2);
-    hipStream_t st = (hipStream_t)stream;
+    // the four parity classes of the input pixels in ONE launch (their workgroups fill the machine
+    // together: no K split, no fold).  Input pixel (2 a + py, 2 b + px) was seen by output
+    // (a + dy_t, b + dx_t) through tap (r, s) with 2 (a + dy_t) + r - 1 = 2 a + py.
+    TapClassSpec sp[4] = {};
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            // input pixel (2 a + py, 2 b + px) was seen by output (a + dy_t, b + dx_t) through tap (r, s):
-            // 2 (a + dy) + r - 1 = 2 a + py  =>  r = py + 1 - 2 dy
-            int taps[9][3], nt = 0;
+            TapClassSpec &c = sp[py * 2 + px];
+            c.Hidx = (int)((H - py + 1) / 2); c.Widx = (int)((W - px + 1) / 2); c.OOy = py; c.OOx = px;
             for (int r = 0; r < 3; ++r)
                 for (int s = 0; s < 3; ++s) {
                     if (((py + 1 - r) & 1) || ((px + 1 - s) & 1)) continue;
-                    taps[nt][0] = (py + 1 - r) / 2; taps[nt][1] = (px + 1 - s) / 2; taps[nt][2] = r * 3 + s; ++nt;
+                    c.taps[c.ntaps][0] = (py + 1 - r) / 2; c.taps[c.ntaps][1] = (px + 1 - s) / 2;
+                    c.taps[c.ntaps][2] = r * 3 + s;
+                    ++c.ntaps;
                 }
-            const int Hidx = (int)((H - py + 1) / 2), Widx = (int)((W - px + 1) / 2);
-            const int rc = launch_taps(1, dy, wt_t, nullptr, nullptr, 1.f, (int)N, Ho, Wo, (int)Cout, (int)Cin, Hidx, Widx,
-                                       2, py, px, (int)H, (int)W, nt, taps, dx, workspace, workspace_floats, st);
-            if (rc != DATR_OK) return rc;
         }
-    return DATR_OK;
+    (void)workspace; (void)workspace_floats;
+    return launch_taps(1, dy, wt_t, nullptr, nullptr, 1.f, (int)N, Ho, Wo, (int)Cout, (int)Cin, 2, (int)H, (int)W, 4, sp, dx,
+                       nullptr, 0, (hipStream_t)stream);
 }
 
 int datr_conv3x3s2_wgrad_nhwc_f32(const float *x, const float *dy, int64_t N, int64_t H, int64_t W, int64_t Cin,

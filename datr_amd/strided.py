@@ -124,3 +124,32 @@ def conv1x1_s2(x: torch.Tensor, weight: torch.Tensor, bias=None, relu: bool = Fa
         return None
     xs = x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
     return pointwise.conv1x1(xs, weight, bias, relu)
+
+
+_STEM_WEIGHTS = {}
+
+
+def stem_conv_bn_relu(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor):
+    """relu(F.conv2d(x, w[64, 3, 7, 7], stride=2, padding=3) * scale + shift) for the FROZEN stem of a
+    channels_last float32 device image batch in one launch (csrc/stem.hip); None when it does not apply
+    (trainable stem, other shapes / layouts: the caller takes the library path)."""
+    if not (OWN_STRIDED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
+            and tuple(w.shape) == (64, 3, 7, 7) and not w.requires_grad and not x.requires_grad
+            and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()):
+        return None
+    key = (w.data_ptr(), w._version, w.device)
+    wk = _STEM_WEIGHTS.get(key)
+    if wk is None:
+        # [r][s * 3 + c][co], every filter row padded to 22 k with a zero row
+        wk = torch.nn.functional.pad(w.detach().permute(2, 3, 1, 0).reshape(7, 21, 64), (0, 0, 0, 1)).reshape(154, 64).contiguous()
+        _STEM_WEIGHTS.clear()
+        _STEM_WEIGHTS[key] = wk
+    N, _, H, W = x.shape
+    y = torch.empty((N, 64, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32,
+                    memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _native.lib.datr_stem_conv7x7_bn_relu_nhwc_f32(x.data_ptr(), wk.data_ptr(), scale.contiguous().data_ptr(),
+                                                            shift.contiguous().data_ptr(), N, H, W, y.data_ptr(),
+                                                            _native.current_stream_ptr(x.device))
+    _native.check(rc, "stem_conv7x7_bn_relu")
+    return y

@@ -255,6 +255,15 @@ int datr_conv3x3_cout1_backward_f32(const datr_c1_level *levels, int64_t nlevels
                                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ResNet-50 stem (csrc/stem.hip): y = relu(conv7x7(x, stride 2, pad 3) * scale + shift), 3 -> 64
+ * channels, NHWC, forward only -- `conv1` + `bn1` + `relu` of the frozen trunk head
+ * (/root/reference/models/dino/backbone.py:62-72,79-81).  x: [N, H, W, 3]; y: [N, (H + 1) / 2,
+ * (W + 1) / 2, 64]; wk: [154][64] = for every filter row r the 21 (tap s, channel c) weights
+ * W[co][c][r][s] in (s, c) order followed by one zero row; scale / shift: [64]. */
+int datr_stem_conv7x7_bn_relu_nhwc_f32(const float *x, const float *wk, const float *scale, const float *shift,
+                                       int64_t N, int64_t H, int64_t W, float *y, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * 3x3 / stride 2 / pad 1 convolutions on NHWC tensors (csrc/conv_tap.hip): `conv2` of the first
  * bottleneck of layer2-4 (/root/reference/models/dino/backbone.py:109-128: torchvision resnet50) and
  * `input_proj[3]` (/root/reference/models/dino/dino.py:120-124: Conv2d(2048, 256, 3, stride 2,

@@ -91,3 +91,21 @@ def test_conv_s2_is_bitwise_reproducible():
         outs.append((y.detach().clone(), xg.grad.clone(), wg.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 37, 53), (2, 200, 333)])
+def test_stem_matches_float64(N, H, W):
+    """conv1 + bn1 + relu of the frozen trunk head (backbone.py:62-72,79-81) in one launch."""
+    from datr_amd.strided import stem_conv_bn_relu
+    g = torch.Generator().manual_seed(H + W)
+    dev = torch.device("cuda:0")
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.1
+    ref = (F.conv2d(x.double(), w.double(), stride=2, padding=3) * scale.double().view(1, -1, 1, 1)
+           + shift.double().view(1, -1, 1, 1)).relu()
+    y = stem_conv_bn_relu(x.to(dev).contiguous(memory_format=torch.channels_last), w.to(dev), scale.to(dev), shift.to(dev))
+    assert y is not None and y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    err = (y.cpu() - ref.float()).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item() + 1e-6, err
