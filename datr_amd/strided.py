@@ -15,6 +15,7 @@ are not the kernels' (the caller then takes the library path).
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -137,13 +138,15 @@ def stem_conv_bn_relu(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shi
             and tuple(w.shape) == (64, 3, 7, 7) and not w.requires_grad and not x.requires_grad
             and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()):
         return None
-    key = (w.data_ptr(), w._version, w.device)
-    wk = _STEM_WEIGHTS.get(key)
-    if wk is None:
+    # the re-laid-out frozen weights are cached per tensor OBJECT (weak reference) and version: a
+    # data pointer alone comes back for a different tensor once the first one is freed
+    hit = _STEM_WEIGHTS.get("w")
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        wk = hit[2]
+    else:
         # [r][s * 3 + c][co], every filter row padded to 22 k with a zero row
         wk = torch.nn.functional.pad(w.detach().permute(2, 3, 1, 0).reshape(7, 21, 64), (0, 0, 0, 1)).reshape(154, 64).contiguous()
-        _STEM_WEIGHTS.clear()
-        _STEM_WEIGHTS[key] = wk
+        _STEM_WEIGHTS["w"] = (weakref.ref(w), (w._version, w.data_ptr()), wk)
     N, _, H, W = x.shape
     y = torch.empty((N, 64, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last)

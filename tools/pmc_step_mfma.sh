@@ -27,6 +27,9 @@ def family(n):
     if "wino_wgrad_nhwc" in n: return "own Winograd weight gradient (wino_wgrad.hip)"
     if "wino_conv" in n: return "own Winograd convolutions (wino.hip)"
     if "wgrad_k256" in n: return "own 256x256 weight gradient (wgrad_k256.hip)"
+    if "tap_wgrad(" in n: return "own stride-2 weight gradient (conv_tap.hip)"
+    if "tap_conv" in n: return "own stride-2 convolutions fwd + dgrad (conv_tap.hip)"
+    if "stem_conv" in n: return "own stem convolution (stem.hip)"
     if "mha_" in n: return "own attention fwd + bwd (mha_fwd.hip, mha_bwd.hip)"
     if "igemm_wrw" in n or "bwd_weight" in n: return "MIOpen convolution weight gradients"
     if "igemm_fwd" in n or "conv_fwd" in n or "Sp3AsmConv" in n: return "MIOpen convolution forward"
