@@ -516,6 +516,31 @@ __global__ __launch_bounds__(256) void tap_wgrad_fold(const float *__restrict__ 
     dw[co * s_co + ci * s_ci + (t / KS) * s_r + (t % KS) * s_s] = s;
 }
 
+// Both filter layouts of a launch pair from torch's [co][ci][3][3] in ONE pass: wt[t][ci][co] for the
+// forward, wt_t[t][co][ci] for the data gradient.  A 32 x 32 (co, ci) tile per workgroup goes through
+// LDS so that both outputs are written in 128-B runs (ATen's strided permute copy took 60-100 us per
+// layout for the 2048 x 256 filter).
+__global__ __launch_bounds__(256) void tap_weights(const float *__restrict__ w, int Cout, int Cin, int64_t s_co,
+                                                   int64_t s_ci, int64_t s_r, int64_t s_s, float *__restrict__ wt,
+                                                   float *__restrict__ wt_t)
+{
+    __shared__ float tile[9][32][33];
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int a = threadIdx.x >> 5, b = threadIdx.x & 31;          // 8 x 32
+    for (int i = a; i < 32; i += 8) {                               // i = co row, b = ci column
+        const float *src = w + (co0 + i) * s_co + (ci0 + b) * s_ci;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) tile[t][i][b] = src[(t / 3) * s_r + (t % 3) * s_s];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        for (int i = a; i < 32; i += 8) {
+            if (wt_t) wt_t[((size_t)t * Cout + co0 + i) * Cin + ci0 + b] = tile[t][i][b];
+            if (wt) wt[((size_t)t * Cin + ci0 + i) * Cout + co0 + b] = tile[t][b][i];
+        }
+}
+
 int wgrad_slices(long N, long Ho, long Wo, long Cin, long Cout) {
     const long tiles = N * ((Ho + WTH - 1) / WTH) * ((Wo + WTW - 1) / WTW);
     const long blocks = (Cin / WCI) * (Cout / WCO);
@@ -537,6 +562,16 @@ int64_t datr_conv3x3s2_workspace_floats(int64_t N, int64_t H, int64_t W, int64_t
     const int64_t fwd = kf > 1 ? kf * N * Ho * Wo * Cout : 0;            // split-K partial sums of the forward
     const int64_t wgr = (int64_t)wgrad_slices(N, Ho, Wo, Cin, Cout) * 9 * Cin * Cout;
     return std::max(fwd, wgr);
+}
+
+int datr_conv3x3s2_weights_f32(const float *w, int64_t Cout, int64_t Cin, int64_t s_co, int64_t s_ci, int64_t s_r,
+                               int64_t s_s, float *wt, float *wt_t, void *stream)
+{
+    if (!w || (!wt && !wt_t) || Cout < 1 || Cin < 1) return DATR_EINVAL;
+    if (Cout % 32 || Cin % 32) return DATR_EUNSUPPORTED;
+    hipLaunchKernelGGL(tap_weights, dim3((unsigned)(Cin / 32), (unsigned)(Cout / 32)), dim3(256), 0, (hipStream_t)stream, w,
+                       (int)Cout, (int)Cin, s_co, s_ci, s_r, s_s, wt, wt_t);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 
 int datr_conv3x3s2_forward_nhwc_f32(const float *x, const float *wt, const float *scale, const float *shift,

@@ -7,8 +7,9 @@ convolution of the C5 map (/root/reference/models/dino/dino.py:120-124).
   * `conv3x3_s2` runs the 3x3 layers -- forward with the frozen batch norm / bias and the ReLU in the
     epilogue, data gradient, weight gradient -- on the own MFMA kernels (csrc/conv_tap.hip,
     `datr_conv3x3s2_{forward,dgrad,wgrad}_nhwc_f32`);
-  * `conv1x1_s2` gathers the even pixels (one strided copy of a quarter of the tensor) and takes the
-    GEMM path of every other 1x1 convolution (datr_amd.pointwise).
+  * `conv1x1_s2` gathers the even pixels (csrc/subsample.hip: one streaming pass over a quarter of the
+    tensor; the adjoint writes the gradient with its zeros in one pass) and takes the GEMM path of every
+    other 1x1 convolution (datr_amd.pointwise).
 Both return None when the tensor is not a channels_last float32 device tensor or the channel counts
 are not the kernels' (the caller then takes the library path).
 """
@@ -44,7 +45,16 @@ class _Conv3x3S2(Function):
         N, C, H, W = x.shape
         co = w.shape[0]
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
-        wt = w.permute(2, 3, 1, 0).contiguous()                      # [3, 3, Cin, Cout]
+        # both filter layouts in one pass: [9][Cin][Cout] for this launch, [9][Cout][Cin] for the data gradient
+        need_t = ctx.needs_input_grad[0]
+        wt = torch.empty(9 * C * co, device=x.device, dtype=torch.float32)
+        wt_t = torch.empty(9 * C * co, device=x.device, dtype=torch.float32) if need_t else None
+        sw = w.stride()
+        with torch.cuda.device(x.device):
+            rc = _native.lib.datr_conv3x3s2_weights_f32(w.data_ptr(), co, C, sw[0], sw[1], sw[2], sw[3], wt.data_ptr(),
+                                                        0 if wt_t is None else wt_t.data_ptr(),
+                                                        _native.current_stream_ptr(x.device))
+        _native.check(rc, "conv3x3s2_weights")
         y = torch.empty((N, co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         ws = _workspace(x.shape, co, x.device)
         with torch.cuda.device(x.device):
@@ -53,14 +63,14 @@ class _Conv3x3S2(Function):
                 0 if shift is None else shift.data_ptr(), 0.0 if relu else 1.0, N, H, W, C, co,
                 y.data_ptr(), ws.data_ptr(), ws.numel(), _native.current_stream_ptr(x.device))
         _native.check(rc, "conv3x3s2_forward")
-        ctx.save_for_backward(x, w, y if relu else None, scale)
+        ctx.save_for_backward(x, w, y if relu else None, scale, wt_t)
         ctx.relu, ctx.bias_grad = bool(relu), scale is None and shift is not None
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, w, y, scale = ctx.saved_tensors
+        x, w, y, scale, wt_t = ctx.saved_tensors
         N, C, H, W = x.shape
         co = w.shape[0]
         need = ctx.needs_input_grad
@@ -82,7 +92,6 @@ class _Conv3x3S2(Function):
         ws = _workspace(x.shape, co, x.device)
         with torch.cuda.device(dy.device):
             if need[0]:
-                wt_t = w.permute(2, 3, 0, 1).contiguous()             # [3, 3, Cout, Cin]
                 dx = torch.empty_like(x, memory_format=torch.channels_last)
                 rc = _native.lib.datr_conv3x3s2_dgrad_nhwc_f32(dz.data_ptr(), wt_t.data_ptr(), N, H, W, C, co,
                                                                dx.data_ptr(), ws.data_ptr(), ws.numel(), stream)
@@ -98,6 +107,35 @@ class _Conv3x3S2(Function):
             from .fused import column_sums
             db = column_sums(dz.permute(0, 2, 3, 1).reshape(-1, co))
         return dx, dw, None, db, None
+
+
+class _EvenPixels(Function):
+    """x[:, :, ::2, ::2] of a channels_last tensor as a dense channels_last tensor (csrc/subsample.hip);
+    the backward writes the whole gradient in one pass (zeros on the odd pixels)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32,
+                        memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = _native.lib.datr_even_pixels_nhwc_f32(x.data_ptr(), N, H, W, C, y.data_ptr(),
+                                                       _native.current_stream_ptr(x.device))
+        _native.check(rc, "even_pixels")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+        with torch.cuda.device(dy.device):
+            rc = _native.lib.datr_even_pixels_scatter_nhwc_f32(dy.data_ptr(), N, H, W, C, dx.data_ptr(),
+                                                               _native.current_stream_ptr(dy.device))
+        _native.check(rc, "even_pixels_scatter")
+        return dx
 
 
 def conv3x3_s2(x: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: bool = False):
@@ -123,8 +161,9 @@ def conv1x1_s2(x: torch.Tensor, weight: torch.Tensor, bias=None, relu: bool = Fa
     if not (OWN_STRIDED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         return None
-    xs = x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
-    return pointwise.conv1x1(xs, weight, bias, relu)
+    if x.shape[1] % 4:
+        return None
+    return pointwise.conv1x1(_EvenPixels.apply(x), weight, bias, relu)
 
 
 _STEM_WEIGHTS = {}

@@ -255,6 +255,15 @@ int datr_conv3x3_cout1_backward_f32(const datr_c1_level *levels, int64_t nlevels
                                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Even pixels of an NHWC tensor and the adjoint (csrc/subsample.hip): what the 1x1 / stride-2
+ * downsample convolutions of layer2-4.0 (/root/reference/models/dino/backbone.py:109-128) read in
+ * front of their GEMM, and the gradient's way back.  x / dx: [N, H, W, C]; y / dy: [N, (H + 1) / 2,
+ * (W + 1) / 2, C]; C % 4 == 0.  The scatter writes ALL of dx (zeros on the odd pixels). */
+int datr_even_pixels_nhwc_f32(const float *x, int64_t N, int64_t H, int64_t W, int64_t C, float *y, void *stream);
+int datr_even_pixels_scatter_nhwc_f32(const float *dy, int64_t N, int64_t H, int64_t W, int64_t C, float *dx,
+                                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * ResNet-50 stem (csrc/stem.hip): y = relu(conv7x7(x, stride 2, pad 3) * scale + shift), 3 -> 64
  * channels, NHWC, forward only -- `conv1` + `bn1` + `relu` of the frozen trunk head
  * (/root/reference/models/dino/backbone.py:62-72,79-81).  x: [N, H, W, 3]; y: [N, (H + 1) / 2,
@@ -279,6 +288,10 @@ int datr_stem_conv7x7_bn_relu_nhwc_f32(const float *x, const float *wk, const fl
  * `workspace`: datr_conv3x3s2_workspace_floats(...) floats of scratch (split-K partial sums, added in
  * a fixed order: results are bitwise reproducible). */
 int64_t datr_conv3x3s2_workspace_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout);
+/* wt and / or wt_t (either may be NULL) from a filter addressed w[co * s_co + ci * s_ci + r * s_r + s * s_s];
+ * Cin % 32 == 0, Cout % 32 == 0. */
+int datr_conv3x3s2_weights_f32(const float *w, int64_t Cout, int64_t Cin, int64_t s_co, int64_t s_ci, int64_t s_r,
+                               int64_t s_s, float *wt, float *wt_t, void *stream);
 int datr_conv3x3s2_forward_nhwc_f32(const float *x, const float *wt, const float *scale, const float *shift,
                                     float slope, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                     float *y, float *workspace, int64_t workspace_floats, void *stream);
