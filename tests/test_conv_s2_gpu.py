@@ -28,6 +28,7 @@ CASES = [
     (4, 2048, 256, 25, 42, 3, False, False, True),    # input_proj[3] at its step size (split K x 16)
     (2, 256, 512, 40, 56, 1, True, False, False),     # layer2.0.downsample
     (2, 1024, 2048, 13, 21, 1, True, False, False),   # layer4.0.downsample
+    (2, 128, 128, 256, 512, 3, True, True, False),    # layer2.0.conv2 at the C2F geometry (1024 x 2048 frames)
     (1, 128, 128, 1, 1, 3, False, False, False),      # a single pixel
     (1, 128, 128, 8, 17, 3, False, False, True),
 ]
@@ -93,7 +94,7 @@ def test_conv_s2_is_bitwise_reproducible():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 37, 53), (2, 200, 333)])
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 37, 53), (2, 200, 333), (1, 1024, 2048)])
 def test_stem_matches_float64(N, H, W):
     """conv1 + bn1 + relu of the frozen trunk head (backbone.py:62-72,79-81) in one launch."""
     from datr_amd.strided import stem_conv_bn_relu
