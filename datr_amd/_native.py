@@ -71,6 +71,7 @@ _SIGNATURES = {
     "datr_wino_weights_f32": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
     "datr_conv3x3_wino_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, _vp],
+    "datr_add_n_f32": [_vp, _i64, _i64, _vp, _vp],
     "datr_even_pixels_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp],
     "datr_even_pixels_scatter_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp],
     "datr_stem_conv7x7_bn_relu_nhwc_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp],

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -395,6 +396,55 @@ def topk_rows(scores: torch.Tensor, k: int):
                                             _native.current_stream_ptr(x.device))
     _native.check(rc, "topk_rows")
     return scores.gather(1, idx) if scores.requires_grad or scores.dtype != torch.float32 else val, idx
+
+
+FAN_OUT = os.environ.get("DATR_FAN_OUT", "1") != "0"
+
+
+class _FanOut(torch.autograd.Function):
+    """n aliases of x for n consumers; the backward adds their gradients in ONE pass (csrc/addn.hip)
+    where autograd would add them pairwise (n - 1 launches of 3 passes each)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        ref = live[0]
+        if not (ref.is_cuda and ref.dtype == torch.float32 and 2 <= len(live) <= 8
+                and all(g.shape == ref.shape and g.dtype == ref.dtype for g in live)):
+            total = live[0]
+            for g in live[1:]:
+                total = total + g
+            return total, None
+        # same dense layout for all (e.g. six transposed views of contiguous gradients): sum in storage order
+        out = torch.empty_like(ref)
+        if out.stride() != ref.stride() or any(g.stride() != ref.stride() for g in live):
+            live = [g.contiguous() for g in live]
+            ref = live[0]
+            out = torch.empty_like(ref)
+        ptrs = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
+        with torch.cuda.device(ref.device):
+            rc = _native.lib.datr_add_n_f32(ctypes.addressof(ptrs), len(live), ref.numel(), out.data_ptr(),
+                                            _native.current_stream_ptr(ref.device))
+        _native.check(rc, "add_n")
+        return out, None
+
+
+def fan_out(x: torch.Tensor, n: int):
+    """n handles on x, one per consumer, whose gradients are summed by one kernel; plain references when
+    x needs no gradient or is not a float32 device tensor."""
+    if not (FAN_OUT and n >= 2 and n <= 8 and x.is_cuda and x.dtype == torch.float32 and x.requires_grad
+            and torch.is_grad_enabled()):
+        return (x,) * n
+    return _FanOut.apply(x, n)
 
 
 def column_sums(x2: torch.Tensor) -> torch.Tensor:

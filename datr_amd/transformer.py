@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .fused import FastLinear
-from .fused import attention_d32, layer_norm
+from .fused import attention_d32, fan_out, layer_norm
 from .fused import linear as fused_linear
 from .msda import MSDeformAttn
 from .nested import inverse_sigmoid
@@ -239,8 +239,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
                 key_padding_mask=None):
-        q = src if pos is None else src + pos
-        src = _add_norm(src, self.self_attn(q, reference_points, src, spatial_shapes,
+        # three consumers of src (query, value projection, residual): one alias each, their gradients
+        # meet in one pass (fused.fan_out) instead of two pairwise adds over the token tensor
+        s_q, s_v, s_r = fan_out(src, 3)
+        q = s_q if pos is None else s_q + pos
+        src = _add_norm(s_r, self.self_attn(q, reference_points, s_v, spatial_shapes,
                                             level_start_index, key_padding_mask),
                         self.dropout1, self.norm1)
         return _ffn_block(src, self.linear1, self.activation, self.dropout2, self.linear2, self.dropout3, self.norm2)
@@ -283,8 +286,10 @@ class TransformerEncoder(nn.Module):
             reference_points = self.get_reference_points(
                 shapes_list if shapes_list is not None else spatial_shapes, valid_ratios,
                 device=src.device)
-        for layer in self.layers:
-            output = layer(src=output, pos=pos, reference_points=reference_points,
+        # the position table feeds every layer: one alias per layer, one gradient sum
+        pos_l = fan_out(pos, len(self.layers)) if (pos is not None and 2 <= len(self.layers) <= 8) else None
+        for li, layer in enumerate(self.layers):
+            output = layer(src=output, pos=pos if pos_l is None else pos_l[li], reference_points=reference_points,
                            spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                            key_padding_mask=key_padding_mask)
         if self.norm is not None:
@@ -399,6 +404,8 @@ class TransformerDecoder(nn.Module):
             tgt_mask = cached[1]
         reference_points = refpoints_unsigmoid.sigmoid()
         ref_points = [reference_points]
+        # the memory feeds every layer's value projection: one alias per layer, one gradient sum
+        mem_l = fan_out(memory, len(self.layers)) if 2 <= len(self.layers) <= 8 else (memory,) * len(self.layers)
         for layer_id, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 4:
                 ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[None, :]
@@ -409,7 +416,7 @@ class TransformerDecoder(nn.Module):
             output = layer(tgt=output, tgt_query_pos=query_pos,
                            tgt_query_sine_embed=query_sine_embed,
                            tgt_key_padding_mask=tgt_key_padding_mask,
-                           tgt_reference_points=ref_in, memory=memory,
+                           tgt_reference_points=ref_in, memory=mem_l[layer_id],
                            memory_key_padding_mask=memory_key_padding_mask,
                            memory_level_start_index=level_start_index,
                            memory_spatial_shapes=spatial_shapes, memory_pos=pos,

@@ -255,6 +255,15 @@ int datr_conv3x3_cout1_backward_f32(const datr_c1_level *levels, int64_t nlevels
                                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * out = xs[0] + ... + xs[n - 1] (2 <= n <= 8 contiguous fp32 tensors of `numel` elements, summed in
+ * argument order) in one pass (csrc/addn.hip): the gradient of a tensor with several consumers --
+ * what autograd's pairwise accumulation does in n - 1 launches for the sources of an encoder layer,
+ * the position table and the decoder's memory
+ * (/root/reference/models/dino/deformable_transformer.py:796-806, 880-900).  `xs`: HOST array of
+ * device pointers. */
+int datr_add_n_f32(const float *const *xs, int64_t n, int64_t numel, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Even pixels of an NHWC tensor and the adjoint (csrc/subsample.hip): what the 1x1 / stride-2
  * downsample convolutions of layer2-4.0 (/root/reference/models/dino/backbone.py:109-128) read in
  * front of their GEMM, and the gradient's way back.  x / dx: [N, H, W, C]; y / dy: [N, (H + 1) / 2,

@@ -510,3 +510,31 @@ def test_ffn_block_as_one_node_matches_composition_and_float64(rows):
         off = (a.double() - r).abs() > 2e-5 * scale + 1e-6
         assert float(off.double().mean()) <= 2e-3 and float((a.double() - r).abs().max()) <= 0.05 * scale
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6
+
+
+@pytest.mark.parametrize("n", [2, 3, 6, 8])
+@pytest.mark.parametrize("shape,transposed", [((4, 1111, 256), False), ((3, 5, 7), False), ((4, 300, 256), True)])
+def test_fan_out_sums_the_consumers_gradients_in_argument_order(n, shape, transposed):
+    """fused.fan_out: n aliases of a tensor whose gradients meet in one csrc/addn.hip pass -- the same
+    sum, in the same order, as autograd's pairwise accumulation (deformable_transformer.py:796-806: src
+    feeds the query, the value projection and the residual)."""
+    from datr_amd.fused import fan_out
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+    ws = [torch.randn(shape, generator=g).to(dev) for _ in range(n)]
+    xin = x.transpose(0, 1) if transposed else x
+    parts = fan_out(xin, n)
+    assert all(p.data_ptr() == xin.data_ptr() for p in parts)
+    sum((p.transpose(0, 1) if transposed else p).mul(w).sum() for p, w in zip(parts, ws)).backward()
+    expect = ws[0].clone()
+    for w in ws[1:]:
+        expect = expect + w                     # argument order
+    assert torch.equal(x.grad, expect)
+
+
+def test_fan_out_passes_through_without_gradient():
+    from datr_amd.fused import fan_out
+    x = torch.randn(5, 3, device="cuda:0")
+    a, b = fan_out(x, 2)
+    assert a is x and b is x
