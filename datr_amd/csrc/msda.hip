@@ -695,7 +695,8 @@ static int backward_tiled_impl(const float *grad_out, const float *value, const 
                                const int64_t *level_start_host, const float *loc,
                                const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
                                int64_t L, int64_t Lq, int64_t P, float *grad_value,
-                               float *grad_loc, float *grad_attn, void *stream, bool allow_pyr) {
+                               float *grad_loc, float *grad_attn, void *stream, bool allow_pyr,
+                               const float *envelope_host = nullptr) {
     // The tiled kernel needs the level geometry on the host (grid size, window maths); anything
     // it does not cover takes the row kernel.
     DatrTiledMeta meta;
@@ -719,7 +720,7 @@ static int backward_tiled_impl(const float *grad_out, const float *value, const 
     static const bool pyr_bwd = !(getenv("DATR_MSDA_PYR_BWD") && atoi(getenv("DATR_MSDA_PYR_BWD")) == 0);
     if (Lq == S && pyr_bwd && allow_pyr) {
         const int rc = datr_internal_msda_bwd_pyr_d32(grad_out, value, loc, attn, shapes_host,
-                                                      level_start_host, N, S, M, D, L, Lq, P,
+                                                      level_start_host, N, S, M, D, L, Lq, P, envelope_host,
                                                       grad_value, grad_loc, grad_attn, stream);
         if (rc != DATR_EUNSUPPORTED) return rc;
     }
@@ -735,6 +736,16 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
                                  float *grad_loc, float *grad_attn, void *stream) {
     return backward_tiled_impl(grad_out, value, shapes, level_start, shapes_host, level_start_host, loc, attn, N,
                                S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, stream, true);
+}
+
+int datr_msda_backward_pyramid_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                                   const int64_t *level_start, const int64_t *shapes_host,
+                                   const int64_t *level_start_host, const float *envelope_host, const float *loc,
+                                   const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
+                                   int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                   float *grad_loc, float *grad_attn, void *stream) {
+    return backward_tiled_impl(grad_out, value, shapes, level_start, shapes_host, level_start_host, loc, attn, N,
+                               S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, stream, true, envelope_host);
 }
 
 int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,

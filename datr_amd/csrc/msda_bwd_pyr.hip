@@ -30,6 +30,7 @@
 // fp32 rounding, not bitwise (the reference's atomicAdd is no different).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 
@@ -440,8 +441,14 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
 }  // namespace
 
 // Region plan of the backward kernel; false when the shape is not covered.
+// `envelope_host` ([8 heads][4 levels]{oy_lo, oy_hi, ox_lo, ox_hi} in pixels of the sampled level, or
+// NULL): the measured reach of the samples (datr_amd/msda.py OffsetMonitor, the forward's window
+// envelope).  With it the windows are exactly as wide as the samples reach; without it they are made as
+// wide as the 1024-row histogram allows.  Either way a sample outside its window takes the direct-atomic
+// path: results never depend on it.
 static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t *level_start_host,
-                         int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P) {
+                         int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                         const float *envelope_host = nullptr) {
     if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || N < 1) return false;
     static const float halo = pyr_halo_from_env();
     const auto fits = [](const PyrMeta &m_, int most_queries) {
@@ -449,12 +456,35 @@ static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t 
         for (int l = 0; l < 4; ++l) rows = std::max(rows, m_.WH[l] * m_.WW[l]);
         return rows <= kMaxRows && rows + 1 <= 2 * kThreads && most_queries <= kMaxQ;
     };
+    if (envelope_host && M <= 8) {
+        // Window rows cost histogram zeroing, scan and flush bookkeeping per level and workgroup:
+        // 697 -> 632 us per N = 4 call at the model's offsets with 4.5 px instead of the widest halo
+        // that fits (tools/probes/bwd_halo.sh; 3.5 px, too tight, sends samples down the slow path: 1835 us).
+        // the envelope is a 0.5 % .. 99.5 % range: a margin keeps most of the stragglers off the slow path
+        constexpr float kEnvelopeMargin = 0.5f;
+        float h4[4];
+        bool sane = true;
+        for (int l = 0; l < 4; ++l) {
+            float r = 0.f;
+            for (int m_ = 0; m_ < (int)M; ++m_)
+                for (int k = 0; k < 4; ++k) {
+                    const float v = envelope_host[(m_ * 4 + l) * 4 + k];
+                    if (!(v == v)) sane = false;
+                    r = std::max(r, std::fabs(v));
+                }
+            h4[l] = std::min(std::max(r + kEnvelopeMargin, 1.0f), 12.0f);
+        }
+        if (sane && build_pyr_meta(pm, shapes_host, level_start_host, S, h4, kMaxQ >= 512 ? 12.5 : 10.0,
+                                   kMaxQ >= 512 ? 28.0 : 16.7, fits))
+            return true;
+    }
     if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, kMaxQ >= 512 ? 12.5 : 10.0,
                         kMaxQ >= 512 ? 28.0 : 16.7, fits))
         return false;
     // The windows are index spaces here (nothing is staged), so the halo may be as wide as the
     // 1024-row histogram allows: samples beyond it take the slow direct-atomic path.
-    {
+    static const bool widen = !(getenv("DATR_MSDA_PYRB_WIDEN") && atoi(getenv("DATR_MSDA_PYRB_WIDEN")) == 0);
+    if (widen) {
         static const float wide[3][4] = {{6.f, 8.f, 10.f, 12.f}, {5.5f, 7.f, 9.f, 11.f}, {5.f, 6.f, 7.f, 8.f}};
         for (int i = 0; i < 3; ++i) {
             float h4[4];
@@ -483,11 +513,11 @@ extern "C" int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const
 extern "C" int datr_internal_msda_bwd_pyr_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
-    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value, float *grad_loc,
-    float *grad_attn, void *stream)
+    int64_t D, int64_t L, int64_t Lq, int64_t P, const float *envelope_host, float *grad_value,
+    float *grad_loc, float *grad_attn, void *stream)
 {
     PyrMeta pm;
-    if (!bwd_pyr_plan(pm, shapes_host, level_start_host, N, S, M, D, L, Lq, P)) return DATR_EUNSUPPORTED;
+    if (!bwd_pyr_plan(pm, shapes_host, level_start_host, N, S, M, D, L, Lq, P, envelope_host)) return DATR_EUNSUPPORTED;
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     kLdsBytes) == hipSuccess;

@@ -559,8 +559,12 @@ extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, cons
             for (int k = 0; k < 4; k += 2) {
                 float &lo = env.v[m_][l][k], &hi = env.v[m_][l][k + 1];
                 if (!(lo == lo) || !(hi == hi) || lo > hi) { lo = -4.5f; hi = 4.5f; }
-                lo = std::max(lo, -24.f);
-                hi = std::min(hi, 24.f);
+                // Wider than the symmetric default does not pay in the forward: the windows grow into
+                // extra phases while a sample beyond them only costs a global gather (offsets ~ N(0, 2.5 px):
+                // 199 us with the measured +-6.4 px envelope, 153 us with +-4.5; tools/probes/bwd_halo.sh)
+                static const float clip = getenv("DATR_MSDA_PYR2_ENV_CLIP") ? (float)atof(getenv("DATR_MSDA_PYR2_ENV_CLIP")) : 4.75f;
+                lo = std::min(std::max(lo, -clip), clip);
+                hi = std::max(std::min(hi, clip), -clip);
             }
     // The grid search costs ~1 ms of host time: plans are cached (geometry + envelope -> plan).
     // The cache is the library's only mutable state; it is guarded and holds plain data.

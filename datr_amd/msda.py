@@ -146,9 +146,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                            grad_output, im2col_step: int, route: int = 0):
+                            grad_output, im2col_step: int, route: int = 0, envelope=None):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight].
-    route: 0 = kernel by geometry; 1 = no pyramid-region kernel; 2 = the row kernel."""
+    route: 0 = kernel by geometry; 1 = no pyramid-region kernel; 2 = the row kernel.
+    envelope: the forward's measured offset envelope (numpy float32 [8, 4, 4]) or None; sizes the windows of
+    the encoder calls' pyramid-region kernel, never changes a result."""
     for t, nme in ((value, "value"), (spatial_shapes, "spatial_shapes"),
                    (level_start_index, "level_start_index"), (sampling_loc, "sampling_loc"),
                    (attn_weight, "attn_weight"), (grad_output, "grad_output")):
@@ -165,13 +167,23 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             # geometry-dispatched backward (pyramid regions / owner-computes / query tiles): needs
             # the geometry on the host
             sh_host, ls_host = _host_meta(shapes, lsi)
-            entry = (_native.lib.datr_msda_backward_tiled_f32 if route == 0
-                     else _native.lib.datr_msda_backward_query_tiled_f32)
-            rc = entry(
-                grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
-                sh_host.ctypes.data, ls_host.ctypes.data, sampling_loc.data_ptr(),
-                attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-                grad_loc.data_ptr(), grad_attn.data_ptr(), stream)
+            if route == 0:
+                env = None
+                if envelope is not None:
+                    import numpy as np
+                    env = np.ascontiguousarray(envelope, dtype=np.float32)
+                    assert env.shape == (8, 4, 4)
+                rc = _native.lib.datr_msda_backward_pyramid_f32(
+                    grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+                    sh_host.ctypes.data, ls_host.ctypes.data, 0 if env is None else env.ctypes.data,
+                    sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                    grad_loc.data_ptr(), grad_attn.data_ptr(), stream)
+            else:
+                rc = _native.lib.datr_msda_backward_query_tiled_f32(
+                    grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+                    sh_host.ctypes.data, ls_host.ctypes.data, sampling_loc.data_ptr(),
+                    attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                    grad_loc.data_ptr(), grad_attn.data_ptr(), stream)
         else:
             fn = getattr(_native.lib, f"datr_msda_backward_{sfx}")
             rc = fn(grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
@@ -194,6 +206,7 @@ class MSDeformAttnFunction(Function):
                                         sampling_locations, attention_weights, ctx.im2col_step, **kw)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
+        ctx.envelope = envelope
         return output
 
     @staticmethod
@@ -201,6 +214,8 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
         kw = {"route": ctx.route} if ctx.route else {}
+        if ctx.envelope is not None:
+            kw["envelope"] = ctx.envelope
         grad_value, grad_loc, grad_attn = ms_deform_attn_backward(
             value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step, **kw)
         return grad_value, None, None, grad_loc, grad_attn, None, None, None

@@ -96,6 +96,16 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
                                  const float *attn, int64_t N, int64_t S, int64_t M, int64_t D,
                                  int64_t L, int64_t Lq, int64_t P, float *grad_value,
                                  float *grad_loc, float *grad_attn, void *stream);
+/* datr_msda_backward_tiled_f32 with the measured offset envelope of the samples (as for
+ * datr_msda_forward_pyramid_f32: [8][4]{oy_lo, oy_hi, ox_lo, ox_hi} pixels of the sampled level, host
+ * memory, or NULL): the encoder calls' pyramid-region kernel sizes its windows by it.  Results do not
+ * depend on it. */
+int datr_msda_backward_pyramid_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                                   const int64_t *level_start, const int64_t *shapes_host,
+                                   const int64_t *level_start_host, const float *envelope_host,
+                                   const float *loc, const float *attn, int64_t N, int64_t S, int64_t M,
+                                   int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                   float *grad_loc, float *grad_attn, void *stream);
 int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
                                        const int64_t *level_start, const int64_t *shapes_host,
                                        const int64_t *level_start_host, const float *loc,

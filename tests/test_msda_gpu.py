@@ -215,6 +215,36 @@ def test_encoder_backward_full_size_n4_against_oracle(M, O, dev, kind):
     torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
 
 
+@pytest.mark.parametrize("env_kind", ["measured", "tight", "lopsided"])
+def test_encoder_backward_does_not_depend_on_the_envelope(M, O, dev, env_kind):
+    """datr_msda_backward_pyramid_f32 sizes the windows of the pyramid-region backward by the offset
+    envelope; samples beyond them take the direct-atomic path: whatever the envelope (measured, far too
+    tight, one-sided), the gradients are the oracle's."""
+    import numpy as np
+    N, Mh, D, P = 2, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, FULL_SHAPES, P, seed=41)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(42)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    loc = pyramid_locs(FULL_SHAPES, N, Mh, P, 2.0, seed=43)
+    go = torch.randn(N, S, Mh * D, generator=g)
+    d = [t.to(dev) for t in (value, sh, lsi, loc, attn, go)]
+    if env_kind == "measured":
+        env = M.measure_envelope(d[3], d[1])
+        assert env is not None
+    elif env_kind == "tight":
+        env = np.tile(np.array([-1.0, 1.0, -1.0, 1.0], np.float32), (8, 4, 1))
+    else:
+        env = np.tile(np.array([0.0, 9.0, -0.5, 0.5], np.float32), (8, 4, 1))
+    gv, gl, ga = M.ms_deform_attn_backward(d[0], d[1], d[2], d[3], d[4], d[5], 64, envelope=env)
+    rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
+    scale = float(rv.abs().max())
+    torch.testing.assert_close(gv.cpu(), rv, rtol=1e-3, atol=1e-5 * scale)
+    torch.testing.assert_close(ga.cpu(), ra, **tol(torch.float32, 10))
+    keep = off_grid(loc, sh)
+    torch.testing.assert_close(gl.cpu()[keep], rl[keep], **tol(torch.float32, 100))
+
+
 # Cityscapes -> Foggy Cityscapes frames are 1024x2048 after the x1.5 scaling capped at 2048
 # (/root/reference/config/DA/Cityscapes2FoggyCityscapes/coco_transformer_C2F.py:1-7; SURVEY.md A.1):
 # the pyramid the mAP clause of the north star would run at.

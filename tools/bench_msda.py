@@ -108,7 +108,7 @@ def main():
                 plan = msda.pyramid_plan(sh, lsi, N, 8, 32, 4, env)
             kw = {} if env is None else {"envelope": env}
             f = lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64, **kw)
-            b = lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64)
+            b = lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 64, **kw)
             fm, fmin = time_fn(f, args.iters)
             bm, bmin = (0.0, 0.0) if args.fwd_only else time_fn(b, args.iters)
             if os.environ.get("DATR_HIP_LIB", "").endswith("probe.so"):
