@@ -211,8 +211,9 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
         const int Hl = pm.H[l], Wl = pm.W[l], stl = pm.start[l];
-        const int WW = pm.WW[l], WH = pm.WH[l], rows = WW * WH;
-        const int wy0 = pm.wy0[l][ry], wx0 = pm.wx0[l][rx];
+        // the level's window, trimmed to this head's reach (envelope plans; zero trims otherwise)
+        const int WW = pm.WW[l] - pm.cut_x[m & 7][l], WH = pm.WH[l] - pm.cut_y[m & 7][l], rows = WW * WH;
+        const int wy0 = pm.wy0[l][ry] + pm.cut_y0[m & 7][l], wx0 = pm.wx0[l][rx] + pm.cut_x0[m & 7][l];
         const float Hf = (float)Hl, Wf = (float)Wl;
 
         for (int i = tid; i <= rows; i += kThreads) hist[i] = 0;
@@ -475,8 +476,23 @@ static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t 
             h4[l] = std::min(std::max(r + kEnvelopeMargin, 1.0f), 12.0f);
         }
         if (sane && build_pyr_meta(pm, shapes_host, level_start_host, S, h4, kMaxQ >= 512 ? 12.5 : 10.0,
-                                   kMaxQ >= 512 ? 28.0 : 16.7, fits))
+                                   kMaxQ >= 512 ? 28.0 : 16.7, fits)) {
+            // A head looks in one direction (the ring initialisation of ms_deform_attn.py:59-68): trim the
+            // symmetric window [lo - h, hi + h] to the head's [lo + e_lo - margin, hi + e_hi + margin].
+            // floor(a) + floor(b) <= floor(a + b) keeps the integer trims on the safe side.
+            for (int m_ = 0; m_ < (int)M; ++m_)
+                for (int l = 0; l < 4; ++l) {
+                    const float *e = envelope_host + (m_ * 4 + l) * 4;
+                    const int y0 = std::max(0, (int)std::floor(h4[l] + e[0] - kEnvelopeMargin));
+                    const int y1 = std::max(0, (int)std::floor(h4[l] - e[1] - kEnvelopeMargin));
+                    const int x0 = std::max(0, (int)std::floor(h4[l] + e[2] - kEnvelopeMargin));
+                    const int x1 = std::max(0, (int)std::floor(h4[l] - e[3] - kEnvelopeMargin));
+                    const int cy = std::min(y0 + y1, pm.WH[l] - 2), cx = std::min(x0 + x1, pm.WW[l] - 2);
+                    pm.cut_y0[m_][l] = (short)std::min(y0, cy); pm.cut_y[m_][l] = (short)cy;
+                    pm.cut_x0[m_][l] = (short)std::min(x0, cx); pm.cut_x[m_][l] = (short)cx;
+                }
             return true;
+        }
     }
     if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, kMaxQ >= 512 ? 12.5 : 10.0,
                         kMaxQ >= 512 ? 28.0 : 16.7, fits))

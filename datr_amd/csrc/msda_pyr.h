@@ -21,6 +21,9 @@ struct PyrMeta {
     int lds_bytes;
     short yb[4][kPyrMaxR + 1], xb[4][kPyrMaxR + 1];   // query rows / cols of level l in region i: [b[i], b[i+1])
     short wy0[4][kPyrMaxR], wx0[4][kPyrMaxR];    // window origin (may be negative: outside the image)
+    // per-(head, level) trims of the symmetric window (backward, envelope plans): rows / columns cut
+    // at the low side (the origin moves by as much) and in total; zero without an envelope
+    short cut_y0[8][4], cut_x0[8][4], cut_y[8][4], cut_x[8][4];
 };
 
 // ceil(a / b) for b > 0 and any a
@@ -46,6 +49,8 @@ inline bool build_pyr_meta(PyrMeta &pm, const int64_t *sh, const int64_t *ls, in
     // level l must be the coarser the larger l (windows are sized for a pyramid)
     for (int l = 1; l < 4; ++l)
         if (pm.H[l] > pm.H[l - 1] || pm.W[l] > pm.W[l - 1]) return false;
+    for (int m = 0; m < 8; ++m)
+        for (int l = 0; l < 4; ++l) pm.cut_y0[m][l] = pm.cut_x0[m][l] = pm.cut_y[m][l] = pm.cut_x[m][l] = 0;
     const int H0 = pm.H[0], W0 = pm.W[0];
     int nRy = std::min(kPyrMaxR, std::max(1, (int)std::lround(H0 / target_h)));
     int nRx = std::min(kPyrMaxR, std::max(1, (int)std::lround(W0 / target_w)));
