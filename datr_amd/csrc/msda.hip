@@ -709,7 +709,7 @@ static int backward_tiled_impl(const float *grad_out, const float *value, const 
     // value rows and scan the samples -- no global atomics, no zero-fill (msda_bwd_owner.hip)
     if (Lq != S && Lq <= 4096) {
         const int rc = datr_internal_msda_bwd_owner_d32(grad_out, value, loc, attn, &meta, N, S, M, P,
-                                                        Lq, grad_value, grad_loc, grad_attn, stream);
+                                                        Lq, grad_value, M * D, grad_loc, grad_attn, stream);
         if (rc != DATR_EUNSUPPORTED) return rc;
     }
     if (hipMemsetAsync(grad_value, 0, (size_t)(N * S * M * D) * sizeof(float),
@@ -746,6 +746,23 @@ int datr_msda_backward_pyramid_f32(const float *grad_out, const float *value, co
                                    float *grad_loc, float *grad_attn, void *stream) {
     return backward_tiled_impl(grad_out, value, shapes, level_start, shapes_host, level_start_host, loc, attn, N,
                                S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, stream, true, envelope_host);
+}
+
+int datr_msda_backward_strided_f32(const float *grad_out, const float *value, const int64_t *shapes_host,
+                                   const int64_t *level_start_host, const float *loc, const float *attn,
+                                   int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                                   float *grad_value, int64_t grad_value_row_stride, float *grad_loc,
+                                   float *grad_attn, void *stream) {
+    if (!grad_out || !value || !loc || !attn || !grad_value || !grad_loc || !grad_attn || !shapes_host ||
+        !level_start_host)
+        return DATR_EINVAL;
+    if (grad_value_row_stride < M * D || grad_value_row_stride % 4) return DATR_EINVAL;
+    DatrTiledMeta meta;
+    // the owner-computes kernel only: it writes every grad_value row exactly once (no zero fill, no atomics)
+    if (Lq == S || Lq > 4096 || !build_tiled_meta(meta, shapes_host, level_start_host, N, S, M, D, L, Lq, P, true))
+        return DATR_EUNSUPPORTED;
+    return datr_internal_msda_bwd_owner_d32(grad_out, value, loc, attn, &meta, N, S, M, P, Lq, grad_value,
+                                            grad_value_row_stride, grad_loc, grad_attn, stream);
 }
 
 int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,

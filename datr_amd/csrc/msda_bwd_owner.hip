@@ -65,7 +65,7 @@ struct OwnerMeta {
 __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, const OwnerMeta meta, int S,
-    int M, int P, int Lq, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    int M, int P, int Lq, float *__restrict__ grad_value, long gv_row_stride, float *__restrict__ grad_loc,
     float *__restrict__ grad_attn)
 {
     constexpr int D = 32;
@@ -221,13 +221,15 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
     // ---- every owned row is written once, plain coalesced stores (no zero-fill needed) ----------
     {
         const int lane32 = tid & 31, rsub = tid >> 5;
-        float *gbase = grad_value + item;
+        // grad_value rows may sit `gv_row_stride` floats apart (a column slice of a wider buffer that
+        // several calls share: datr_msda_backward_strided_f32); M * D for the plain layout
+        float *gbase = grad_value + (size_t)n * S * gv_row_stride + (size_t)m * D;
         for (int rr = rsub; rr < nrows; rr += kThreads / 32) {
             const long long pk = reinterpret_cast<const long long *>(win + rr * D)[lane32 >> 1];
             const int lo = (int)(unsigned)(pk & 0xffffffffLL);
             const int hi = (int)((pk - (long long)lo) >> 32);
             const float v = (float)((lane32 & 1) ? hi : lo) * inv_scale;
-            gbase[(size_t)(start + p0 + rr) * (M * D) + lane32] = v;
+            gbase[(size_t)(start + p0 + rr) * gv_row_stride + lane32] = v;
         }
     }
 }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
 extern "C" int datr_internal_msda_bwd_owner_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const DatrTiledMeta *tm, int64_t N, int64_t S, int64_t M, int64_t P, int64_t Lq,
-    float *grad_value, float *grad_loc, float *grad_attn, void *stream)
+    float *grad_value, int64_t grad_value_row_stride, float *grad_loc, float *grad_attn, void *stream)
 {
     OwnerMeta meta;
     meta.L = tm->L;
@@ -253,6 +255,6 @@ extern "C" int datr_internal_msda_bwd_owner_d32(
     const size_t lds = kThreads * sizeof(Entry) + (size_t)kRows * 32 * 4 + 16 + 2 * kWaves * 4;
     hipLaunchKernelGGL(msda_bwd_owner_d32, dim3((unsigned)blocks), dim3(kThreads), lds,
                        (hipStream_t)stream, grad_out, value, loc, attn, meta, (int)S, (int)M, (int)P,
-                       (int)Lq, grad_value, grad_loc, grad_attn);
+                       (int)Lq, grad_value, (long)grad_value_row_stride, grad_loc, grad_attn);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }

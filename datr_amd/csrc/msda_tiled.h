@@ -57,4 +57,4 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
 extern "C" int datr_internal_msda_bwd_owner_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const DatrTiledMeta *meta, int64_t N, int64_t S, int64_t M, int64_t P, int64_t Lq,
-    float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+    float *grad_value, int64_t grad_value_row_stride, float *grad_loc, float *grad_attn, void *stream);

@@ -66,6 +66,8 @@ _HOST_META = {}
 # path); everything else the row kernel.  DATR_MSDA_PYR_FWD=0 forces the row kernel (A/B runs).
 TILED_BACKWARD_MIN_LQ = int(__import__("os").environ.get("DATR_MSDA_TILED_BWD_MIN_LQ", "64"))
 MERGE_QUERY_PROJECTIONS = __import__("os").environ.get("DATR_MERGE_QPROJ", "1") != "0"   # A/B switch
+VALUE_PROJ_BATCH = __import__("os").environ.get("DATR_VALUE_PROJ_BATCH", "1") != "0"     # A/B switch
+_EUNSUPPORTED = -2                              # DATR_EUNSUPPORTED of include/datr_hip.h
 PYR_FORWARD = __import__("os").environ.get("DATR_MSDA_PYR_FWD", "1") != "0"
 
 
@@ -146,11 +148,14 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                            grad_output, im2col_step: int, route: int = 0, envelope=None):
+                            grad_output, im2col_step: int, route: int = 0, envelope=None, grad_value_out=None):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight].
     route: 0 = kernel by geometry; 1 = no pyramid-region kernel; 2 = the row kernel.
     envelope: the forward's measured offset envelope (numpy float32 [8, 4, 4]) or None; sizes the windows of
-    the encoder calls' pyramid-region kernel, never changes a result."""
+    the encoder calls' pyramid-region kernel, never changes a result.
+    grad_value_out: optional [N, S, M, D] float32 view whose pixel rows may sit further apart than M * D
+    floats (a column slice of a buffer several calls share, see value_projections): grad_value is written
+    there -- directly by the decoder calls' kernel, through a copy otherwise -- and returned."""
     for t, nme in ((value, "value"), (spatial_shapes, "spatial_shapes"),
                    (level_start_index, "level_start_index"), (sampling_loc, "sampling_loc"),
                    (attn_weight, "attn_weight"), (grad_output, "grad_output")):
@@ -158,9 +163,22 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
     sfx = _suffix(value)
     shapes, lsi = _as_int64(spatial_shapes), _as_int64(level_start_index)
-    grad_value = torch.empty_like(value)            # zero-filled by the library on the stream
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
+    if grad_value_out is not None and sfx == "f32" and D == 32 and route == 0 and Lq != S \
+            and tuple(grad_value_out.shape) == (N, S, M, D) and grad_value_out.stride(3) == 1 \
+            and grad_value_out.stride(2) == D and grad_value_out.stride(0) == S * grad_value_out.stride(1):
+        sh_host, ls_host = _host_meta(shapes, lsi)
+        with torch.cuda.device(value.device):
+            rc = _native.lib.datr_msda_backward_strided_f32(
+                grad_output.data_ptr(), value.data_ptr(), sh_host.ctypes.data, ls_host.ctypes.data,
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value_out.data_ptr(),
+                grad_value_out.stride(1), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                _native.current_stream_ptr(value.device))
+        if rc != _EUNSUPPORTED:
+            _native.check(rc, "ms_deform_attn_backward (strided)")
+            return [grad_value_out, grad_loc, grad_attn]
+    grad_value = torch.empty_like(value)            # zero-filled by the library on the stream
     with torch.cuda.device(value.device):
         stream = _native.current_stream_ptr(value.device)
         if sfx == "f32" and D == 32 and Lq >= TILED_BACKWARD_MIN_LQ and route < 2:
@@ -190,14 +208,18 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                     sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
                     grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), stream)
     _native.check(rc, "ms_deform_attn_backward")
+    if grad_value_out is not None:
+        grad_value_out.copy_(grad_value)
+        grad_value = grad_value_out
     return [grad_value, grad_loc, grad_attn]
 
 
 class MSDeformAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                attention_weights, im2col_step, route=0, envelope=None):
+                attention_weights, im2col_step, route=0, envelope=None, grad_slot=None):
         ctx.im2col_step = im2col_step
+        ctx.grad_slot = grad_slot                    # (GradSlab, index): where grad_value goes (value_projections)
         ctx.route = int(route)
         kw = {"route": ctx.route} if ctx.route else {}
         if envelope is not None:
@@ -216,9 +238,103 @@ class MSDeformAttnFunction(Function):
         kw = {"route": ctx.route} if ctx.route else {}
         if ctx.envelope is not None:
             kw["envelope"] = ctx.envelope
+        if ctx.grad_slot is not None and value.dim() == 4:
+            slab, i = ctx.grad_slot
+            kw["grad_value_out"] = slab.slot(i, value)
         grad_value, grad_loc, grad_attn = ms_deform_attn_backward(
             value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step, **kw)
-        return grad_value, None, None, grad_loc, grad_attn, None, None, None
+        return grad_value, None, None, grad_loc, grad_attn, None, None, None, None
+
+
+class GradSlab:
+    """One [N, S, n * C] buffer for the value gradients of n attention calls on the same memory: call i
+    writes columns i C .. (i + 1) C (its kernel takes the row stride), so that the n value projections'
+    data gradient, weight gradients and bias gradients are ONE GEMM / GEMM / column sum over the buffer
+    instead of n of each plus n - 1 adds over the token tensor."""
+
+    def __init__(self, n: int):
+        self.n, self.buf = n, None
+
+    def slot(self, i: int, value: torch.Tensor) -> torch.Tensor:
+        N, S, M, D = value.shape
+        C = M * D
+        if self.buf is None or tuple(self.buf.shape) != (N, S, self.n * C) or self.buf.device != value.device:
+            self.buf = torch.empty(N, S, self.n * C, device=value.device, dtype=torch.float32)
+        return self.buf[:, :, i * C:(i + 1) * C].view(N, S, M, D)
+
+    def holds(self, grads, C: int) -> bool:
+        b = self.buf
+        if b is None or len(grads) != self.n:
+            return False
+        N, S, _ = b.shape
+        want = (S * self.n * C, self.n * C, 1)
+        return all(g is not None and tuple(g.shape) == (N, S, C) and g.stride() == want
+                   and g.data_ptr() == b.data_ptr() + 4 * i * C for i, g in enumerate(grads))
+
+
+class _ValueProjN(Function):
+    """[memory @ W_i^T + b_i for i in range(n)]: the value projections of the n decoder layers
+    (/root/reference/models/dino/ops/modules/ms_deform_attn.py:96-100 inside
+    deformable_transformer.py:880-900, all on the encoder's memory).  Forward: n GEMMs.  Backward: when the
+    attention calls left their value gradients in the shared GradSlab, ONE data-gradient GEMM (K = n C; its
+    reduction replaces n - 1 adds over the 91 MB token tensor), ONE weight-gradient GEMM and one column sum."""
+
+    @staticmethod
+    def forward(ctx, memory, slab, *wb):
+        n = len(wb) // 2
+        ws, bs = wb[:n], wb[n:]
+        C = memory.shape[-1]
+        m2 = memory.reshape(-1, C)
+        outs = tuple(torch.addmm(b, m2, w.t()).view(*memory.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
+        ctx.save_for_backward(memory, *ws)
+        ctx.slab, ctx.n = slab, n
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        from .fused import column_sums
+        memory, *ws = ctx.saved_tensors
+        n, slab = ctx.n, ctx.slab
+        C = memory.shape[-1]
+        m2 = memory.reshape(-1, C)
+        need = ctx.needs_input_grad
+        if all(w.shape[0] == C for w in ws) and slab.holds(gs, C):
+            buf, slab.buf = slab.buf, None                # the next step gets a fresh buffer
+            g2 = buf.view(-1, n * C)
+            dmem = g2.mm(torch.cat(ws, 0)).view_as(memory) if need[0] else None
+            dws = g2.t().mm(m2).split(C, 0)
+            dbs = column_sums(g2).split(C, 0)
+        else:
+            dmem, dws, dbs = None, [], []
+            for g, w in zip(gs, ws):
+                if g is None:
+                    dws.append(None); dbs.append(None)
+                    continue
+                g2 = g.reshape(-1, w.shape[0])
+                g2 = g2 if g2.is_contiguous() else g2.contiguous()
+                if need[0]:
+                    dmem = g2.mm(w) if dmem is None else dmem.addmm_(g2, w)
+                dws.append(g2.t().mm(m2))
+                dbs.append(column_sums(g2))
+            dmem = None if dmem is None else dmem.view_as(memory)
+        return (dmem, None, *dws, *dbs)
+
+
+def value_projections(memory: torch.Tensor, attns):
+    """(values, slab) for attention modules that all read `memory` ([N, S, C]): values[i] =
+    attns[i].value_proj(memory), computed by one autograd node whose backward is batched over the modules
+    (_ValueProjN); hand values[i] and (slab, i) to attns[i].forward.  None when that does not apply."""
+    if not (VALUE_PROJ_BATCH and 2 <= len(attns) <= 8 and memory.is_cuda and memory.dtype == torch.float32
+            and memory.dim() == 3 and memory.is_contiguous() and torch.is_grad_enabled()
+            and all(isinstance(a, MSDeformAttn) and a.value_proj.bias is not None
+                    and a.value_proj.weight.shape == (memory.shape[-1], memory.shape[-1])
+                    and a.d_model // a.n_heads == 32 for a in attns)):
+        return None
+    slab = GradSlab(len(attns))
+    values = _ValueProjN.apply(memory, slab, *[a.value_proj.weight for a in attns],
+                               *[a.value_proj.bias for a in attns])
+    return values, slab
 
 
 def _is_power_of_2(n: int) -> bool:
@@ -498,13 +614,18 @@ class MSDeformAttn(nn.Module):
         nn.init.constant_(self.output_proj.bias, 0.0)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None):
+                input_level_start_index, input_padding_mask=None, value=None, grad_slot=None):
+        """`value` / `grad_slot`: this module's value projection computed elsewhere (value_projections)
+        and where its gradient is to be left; the reference's signature otherwise."""
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         H = self.n_heads
-        value = self.value_proj(input_flatten)
+        if value is None:
+            value = self.value_proj(input_flatten)
+            grad_slot = None
         if input_padding_mask is not None:
             value = zero_padded_rows(value, input_padding_mask)
+            grad_slot = None
         value = value.view(N, Len_in, H, self.d_model // H)
         fold_wh = False
         if query.is_cuda and MERGE_QUERY_PROJECTIONS:
@@ -538,7 +659,7 @@ class MSDeformAttn(nn.Module):
                     mon.observe(locations, _host_meta(_as_int64(input_spatial_shapes),
                                                       _as_int64(input_level_start_index))[0])
                 out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                                 locations, weights, self.im2col_step, route, envelope)
+                                                 locations, weights, self.im2col_step, route, envelope, grad_slot)
                 return self.output_proj(out)
             n_off = self.sampling_offsets.out_features
             off2, wts2 = _SplitLast.apply(both, n_off)

@@ -24,7 +24,7 @@ from torch import Tensor, nn
 from .fused import FastLinear
 from .fused import attention_d32, fan_out, layer_norm
 from .fused import linear as fused_linear
-from .msda import MSDeformAttn
+from .msda import MSDeformAttn, value_projections
 from .nested import inverse_sigmoid
 
 
@@ -335,25 +335,26 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return _add_norm(tgt, tgt2, self.dropout2, self.norm2)
 
     def forward_ca(self, tgt, query_pos, reference_points, memory, spatial_shapes,
-                   level_start_index, key_padding_mask):
+                   level_start_index, key_padding_mask, value=None, grad_slot=None):
         q = tgt if query_pos is None else tgt + query_pos
+        kw = {} if value is None else {"value": value, "grad_slot": grad_slot}
         tgt2 = self.cross_attn(q.transpose(0, 1), reference_points.transpose(0, 1).contiguous(),
                                memory.transpose(0, 1), spatial_shapes, level_start_index,
-                               key_padding_mask).transpose(0, 1)
+                               key_padding_mask, **kw).transpose(0, 1)
         return _add_norm(tgt, tgt2, self.dropout1, self.norm1)
 
     def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None,
                 tgt_key_padding_mask=None, tgt_reference_points=None, memory=None,
                 memory_key_padding_mask=None, memory_level_start_index=None,
                 memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
-                cross_attn_mask=None):
+                cross_attn_mask=None, memory_value=None, memory_grad_slot=None):
         for name in self.module_seq:
             if name == "ffn":
                 tgt = self.forward_ffn(tgt)
             elif name == "ca":
                 tgt = self.forward_ca(tgt, tgt_query_pos, tgt_reference_points, memory,
                                       memory_spatial_shapes, memory_level_start_index,
-                                      memory_key_padding_mask)
+                                      memory_key_padding_mask, memory_value, memory_grad_slot)
             else:
                 tgt = self.forward_sa(tgt, tgt_query_pos, self_attn_mask)
         return tgt
@@ -404,8 +405,20 @@ class TransformerDecoder(nn.Module):
             tgt_mask = cached[1]
         reference_points = refpoints_unsigmoid.sigmoid()
         ref_points = [reference_points]
-        # the memory feeds every layer's value projection: one alias per layer, one gradient sum
-        mem_l = fan_out(memory, len(self.layers)) if 2 <= len(self.layers) <= 8 else (memory,) * len(self.layers)
+        # The memory feeds every layer's value projection.  All six projections as ONE autograd node
+        # (msda.value_projections): the attention calls leave their value gradients in one shared
+        # buffer and the data / weight / bias gradients of the six projections are one GEMM / GEMM /
+        # column sum.  Otherwise one alias per layer, one gradient sum (fan_out).
+        batched = None
+        if memory_key_padding_mask is None and memory.dim() == 3 \
+                and all(isinstance(getattr(l, "cross_attn", None), MSDeformAttn) for l in self.layers):
+            mem_nsc = memory.transpose(0, 1)
+            if mem_nsc.is_contiguous():
+                batched = value_projections(mem_nsc, [l.cross_attn for l in self.layers])
+        if batched is None:
+            mem_l = fan_out(memory, len(self.layers)) if 2 <= len(self.layers) <= 8 else (memory,) * len(self.layers)
+        else:
+            mem_l = (memory,) * len(self.layers)
         for layer_id, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 4:
                 ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[None, :]
@@ -420,7 +433,9 @@ class TransformerDecoder(nn.Module):
                            memory_key_padding_mask=memory_key_padding_mask,
                            memory_level_start_index=level_start_index,
                            memory_spatial_shapes=spatial_shapes, memory_pos=pos,
-                           self_attn_mask=tgt_mask, cross_attn_mask=memory_mask)
+                           self_attn_mask=tgt_mask, cross_attn_mask=memory_mask,
+                           **({} if batched is None else {"memory_value": batched[0][layer_id],
+                                                          "memory_grad_slot": (batched[1], layer_id)}))
             if self.bbox_embed is not None:
                 # iterative refinement: the next layer starts from this layer's box, detached
                 new_ref = (self.bbox_embed[layer_id](output)

@@ -106,6 +106,16 @@ int datr_msda_backward_pyramid_f32(const float *grad_out, const float *value, co
                                    const float *loc, const float *attn, int64_t N, int64_t S, int64_t M,
                                    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value,
                                    float *grad_loc, float *grad_attn, void *stream);
+/* The decoder calls' backward (few, spatially unordered queries: Lq != S, Lq <= 4096, D == 32) with
+ * grad_value rows `grad_value_row_stride` floats apart (>= M * D): the six decoder layers of
+ * /root/reference/models/dino/deformable_transformer.py:880-900 write their value gradients as column
+ * slices of ONE [N, S, 6 * 256] buffer, so that the six value projections' data and weight gradients are
+ * one GEMM each.  Every row of the slice is written exactly once.  DATR_EUNSUPPORTED for other shapes. */
+int datr_msda_backward_strided_f32(const float *grad_out, const float *value, const int64_t *shapes_host,
+                                   const int64_t *level_start_host, const float *loc, const float *attn,
+                                   int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                                   float *grad_value, int64_t grad_value_row_stride, float *grad_loc,
+                                   float *grad_attn, void *stream);
 int datr_msda_backward_query_tiled_f32(const float *grad_out, const float *value, const int64_t *shapes,
                                        const int64_t *level_start, const int64_t *shapes_host,
                                        const int64_t *level_start_host, const float *loc,

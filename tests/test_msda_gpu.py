@@ -648,3 +648,49 @@ def test_padded_rows_are_zeroed_in_place_like_masked_fill():
     want = v.masked_fill(mask[..., None], 0.0)
     got = msda.zero_padded_rows(v.clone().requires_grad_(True) * 1.0, mask)
     assert torch.equal(got, want)
+
+
+def test_batched_value_projections_match_separate_modules(M, dev):
+    """msda.value_projections: the value projections of several attention modules on one memory as one
+    autograd node whose backward reads the value gradients out of a shared buffer (written with a row
+    stride by datr_msda_backward_strided_f32) -- same outputs, same gradients as the modules one by one
+    (the decoder layers of deformable_transformer.py:880-900)."""
+    torch.manual_seed(7)
+    shapes = [(20, 30), (10, 15), (5, 8), (3, 4)]
+    sh = torch.tensor(shapes, dtype=torch.int64, device=dev)
+    lsi = torch.cat([sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]])
+    S, N, Lq, n = int(sh.prod(1).sum()), 2, 50, 3
+    attns = [M.MSDeformAttn(256, 4, 8, 4).to(dev) for _ in range(n)]
+    for a in attns:                                   # spread the samples: the ring alone sits on grid lines
+        torch.nn.init.normal_(a.sampling_offsets.weight, std=0.02)
+        torch.nn.init.normal_(a.attention_weights.weight, std=0.02)
+    mem0 = torch.randn(N, S, 256, device=dev)
+    qs = [torch.randn(N, Lq, 256, device=dev) for _ in range(n)]
+    ref = torch.rand(N, Lq, 4, 4, device=dev) * 0.6 + 0.2
+    ws = [torch.randn(N, Lq, 256, device=dev) for _ in range(n)]
+
+    def run(batched):
+        for a in attns:
+            a.zero_grad(set_to_none=True)
+        mem = mem0.clone().requires_grad_(True)
+        if batched:
+            res = M.value_projections(mem, attns)
+            assert res is not None
+            values, slab = res
+            outs = [a(q, ref, mem, sh, lsi, None, value=values[i], grad_slot=(slab, i))
+                    for i, (a, q) in enumerate(zip(attns, qs))]
+        else:
+            outs = [a(q, ref, mem, sh, lsi, None) for a, q in zip(attns, qs)]
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        grads = [mem.grad.clone()]
+        for a in attns:
+            grads += [a.value_proj.weight.grad.clone(), a.value_proj.bias.grad.clone(),
+                      a.sampling_offsets.weight.grad.clone(), a.output_proj.weight.grad.clone()]
+        return [o.detach().clone() for o in outs], grads
+
+    o1, g1 = run(False)
+    o2, g2 = run(True)
+    for a, b in zip(o1, o2):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(a.abs().max()))
