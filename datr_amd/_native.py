@@ -36,6 +36,7 @@ _SIGNATURES = {
     "datr_msda_uses_fast_path": [_i64] * 5,
     "datr_affine_act_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
     "datr_affine_act_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
+    "datr_affine_act_backward2_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
     "datr_conv3x3_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
                                  ctypes.c_float, _vp, _vp],
     "datr_add_layernorm_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp],

@@ -81,7 +81,15 @@ class Bottleneck(nn.Module):
                 nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
                 norm_layer(planes * 4))
 
+    # set on every block but the last of a stage (ResNet50Body): the block then returns its output as TWO
+    # handles (for the next block's conv1 and identity branch) whose gradients the frozen-BN backward
+    # kernel adds on the fly; the next block takes the pair apart
+    pair_out = False
+
     def forward(self, x):
+        x_id = x
+        if isinstance(x, tuple):
+            x, x_id = x
         if not isinstance(self.bn1, FrozenBatchNorm2d):       # foreign norm layer: plain path
             identity = x if self.downsample is None else self.downsample(x)
             out = self.relu(self.bn1(self.conv1(x)))
@@ -96,7 +104,7 @@ class Bottleneck(nn.Module):
         folded = getattr(self, "_folded", None) if nhwc else None
         ds_conv = None if self.downsample is None else self.downsample[0]
         if self.downsample is None:
-            identity = x
+            identity = x_id
         else:
             identity = None
             if nhwc and folded is not None and folded[1] is not None:
@@ -127,6 +135,8 @@ class Bottleneck(nn.Module):
         y3 = pointwise.conv1x1(out, self.conv3.weight) if nhwc else None
         if y3 is None:
             y3 = self.conv3(out)
+        if self.pair_out and self.training:
+            return frozen_bn_act(y3, *self.bn3.scale_shift(), residual=identity, relu=True, twice=True)
         return frozen_bn_act(y3, *self.bn3.scale_shift(), residual=identity, relu=True)
 
     def fold_pairs(self):
@@ -155,6 +165,8 @@ class ResNet50Body(nn.Module):
             inplanes = planes * 4
             layers += [Bottleneck(inplanes, planes, 1, norm_layer, downsample=False)
                        for _ in range(blocks - 1)]
+            for blk in layers[:-1]:                  # their successor has no downsample branch: see pair_out
+                blk.pair_out = True
             setattr(self, f"layer{idx}", nn.Sequential(*layers))
         for m in self.modules():
             if isinstance(m, nn.Conv2d):

@@ -69,13 +69,17 @@ __global__ __launch_bounds__(kThreads) void affine_fwd4c(
 
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void affine_bwd4c(
-    const float4 *__restrict__ dy, const float4 *__restrict__ y, const float4 *__restrict__ scale,
-    int64_t n4, int C4, float4 *__restrict__ dx, float4 *__restrict__ dres)
+    const float4 *__restrict__ dy, const float4 *__restrict__ dy2, const float4 *__restrict__ y,
+    const float4 *__restrict__ scale, int64_t n4, int C4, float4 *__restrict__ dx, float4 *__restrict__ dres)
 {
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * kThreads) {
         const float4 s = scale[(int)(i % C4)];
         float4 g = dy[i];
+        if (dy2) {                               // two consumers of y: their gradients meet here
+            const float4 h = dy2[i];
+            g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+        }
         if (RELU) {
             const float4 o = y[i];
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
@@ -103,14 +107,19 @@ __global__ __launch_bounds__(kThreads) void affine_fwd1(
 
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void affine_bwd4(
-    const float4 *__restrict__ dy, const float4 *__restrict__ y, const float *__restrict__ scale,
-    int64_t n4, int C, int64_t inner4, float4 *__restrict__ dx, float4 *__restrict__ dres)
+    const float4 *__restrict__ dy, const float4 *__restrict__ dy2, const float4 *__restrict__ y,
+    const float *__restrict__ scale, int64_t n4, int C, int64_t inner4, float4 *__restrict__ dx,
+    float4 *__restrict__ dres)
 {
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * kThreads) {
         const int c = (int)((i / inner4) % C);
         const float s = scale[c];
         float4 g = dy[i];
+        if (dy2) {
+            const float4 h = dy2[i];
+            g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+        }
         if (RELU) {
             const float4 o = y[i];
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
@@ -123,13 +132,15 @@ __global__ __launch_bounds__(kThreads) void affine_bwd4(
 
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(kThreads) void affine_bwd1(
-    const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ scale,
-    int64_t n, int C, int64_t inner, float *__restrict__ dx, float *__restrict__ dres)
+    const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ y,
+    const float *__restrict__ scale, int64_t n, int C, int64_t inner, float *__restrict__ dx,
+    float *__restrict__ dres)
 {
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * kThreads) {
         const int c = (int)((i / inner) % C);
         float g = dy[i];
+        if (dy2) g += dy2[i];
         if (RELU) g = y[i] > 0.f ? g : 0.f;
         if (RES) dres[i] = g;
         dx[i] = g * scale[c];
@@ -177,35 +188,47 @@ int datr_affine_act_forward_f32(const float *x, const float *res, const float *s
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 
-int datr_affine_act_backward_f32(const float *dy, const float *y, const float *scale, int64_t n,
-                                 int64_t C, int64_t inner, int relu, float *dx, float *dres,
-                                 void *stream) {
+static int affine_backward(const float *dy, const float *dy2, const float *y, const float *scale, int64_t n,
+                           int64_t C, int64_t inner, int relu, float *dx, float *dres, void *stream) {
     if (n < 0 || C <= 0 || inner <= 0) return DATR_EINVAL;
     if (n == 0) return DATR_OK;
     if (!dy || !scale || !dx || (relu && !y)) return DATR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool al = n % 4 == 0 && aligned16(dy) && aligned16(dx) && (!relu || aligned16(y)) &&
-                    (!dres || aligned16(dres));
+                    (!dres || aligned16(dres)) && (!dy2 || aligned16(dy2));
     const bool vec = al && inner % 4 == 0;
     const bool vecc = al && inner == 1 && C % 4 == 0 && aligned16(scale);
 #define DATR_GO(RELU, RES)                                                                        \
     if (vec)                                                                                      \
         hipLaunchKernelGGL((affine_bwd4<RELU, RES>), dim3(grid_for(n / 4)), dim3(kThreads), 0, st, \
-                           (const float4 *)dy, (const float4 *)y, scale, n / 4, (int)C, inner / 4, \
-                           (float4 *)dx, (float4 *)dres);                                         \
+                           (const float4 *)dy, (const float4 *)dy2, (const float4 *)y, scale, n / 4, \
+                           (int)C, inner / 4, (float4 *)dx, (float4 *)dres);                      \
     else if (vecc)                                                                                \
         hipLaunchKernelGGL((affine_bwd4c<RELU, RES>), dim3(grid_for(n / 4)), dim3(kThreads), 0, st, \
-                           (const float4 *)dy, (const float4 *)y, (const float4 *)scale, n / 4,   \
-                           (int)(C / 4), (float4 *)dx, (float4 *)dres);                           \
+                           (const float4 *)dy, (const float4 *)dy2, (const float4 *)y,            \
+                           (const float4 *)scale, n / 4, (int)(C / 4), (float4 *)dx, (float4 *)dres); \
     else                                                                                          \
         hipLaunchKernelGGL((affine_bwd1<RELU, RES>), dim3(grid_for(n)), dim3(kThreads), 0, st, dy, \
-                           y, scale, n, (int)C, inner, dx, dres)
+                           dy2, y, scale, n, (int)C, inner, dx, dres)
     if (relu && dres) { DATR_GO(true, true); }
     else if (relu) { DATR_GO(true, false); }
     else if (dres) { DATR_GO(false, true); }
     else { DATR_GO(false, false); }
 #undef DATR_GO
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+int datr_affine_act_backward_f32(const float *dy, const float *y, const float *scale, int64_t n,
+                                 int64_t C, int64_t inner, int relu, float *dx, float *dres,
+                                 void *stream) {
+    return affine_backward(dy, nullptr, y, scale, n, C, inner, relu, dx, dres, stream);
+}
+
+int datr_affine_act_backward2_f32(const float *dy, const float *dy2, const float *y, const float *scale,
+                                  int64_t n, int64_t C, int64_t inner, int relu, float *dx, float *dres,
+                                  void *stream) {
+    if (!dy2) return DATR_EINVAL;
+    return affine_backward(dy, dy2, y, scale, n, C, inner, relu, dx, dres, stream);
 }
 
 }  // extern "C"

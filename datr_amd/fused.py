@@ -23,7 +23,7 @@ class _AffineAct(Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, scale, shift, res, relu):
+    def forward(ctx, x, scale, shift, res, relu, twice=False):
         N, C, H, W = x.shape
         # NHWC (channels_last) tensors are processed in place of layout: channel = i % C
         nhwc = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
@@ -42,38 +42,56 @@ class _AffineAct(Function):
         ctx.relu, ctx.has_res = bool(relu), res is not None
         ctx.save_for_backward(y if relu else None, scale)
         ctx.shape = (C, inner, fmt)
-        return y
+        # twice: two handles on y for its two consumers (the next bottleneck's conv1 and identity
+        # branch); their gradients are summed inside the backward kernel
+        return (y, y.view_as(y)) if twice else y
 
     @staticmethod
     @once_differentiable
     @_amp_bwd
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         y, scale = ctx.saved_tensors
         C, inner, fmt = ctx.shape
+        if dy is None:
+            dy, dy2 = dy2, None
         dy = dy.contiguous(memory_format=fmt)
+        if dy2 is not None:
+            dy2 = dy2.contiguous(memory_format=fmt)
         dx = torch.empty_like(dy, memory_format=fmt)
         dres = (torch.empty_like(dy, memory_format=fmt)
                 if ctx.has_res and ctx.needs_input_grad[3] else None)
         with torch.cuda.device(dy.device):
-            rc = _native.lib.datr_affine_act_backward_f32(
-                dy.data_ptr(), 0 if y is None else y.data_ptr(), scale.data_ptr(), dy.numel(), C,
-                inner, int(ctx.relu), dx.data_ptr(), 0 if dres is None else dres.data_ptr(),
-                _native.current_stream_ptr(dy.device))
+            if dy2 is None:
+                rc = _native.lib.datr_affine_act_backward_f32(
+                    dy.data_ptr(), 0 if y is None else y.data_ptr(), scale.data_ptr(), dy.numel(), C,
+                    inner, int(ctx.relu), dx.data_ptr(), 0 if dres is None else dres.data_ptr(),
+                    _native.current_stream_ptr(dy.device))
+            else:
+                rc = _native.lib.datr_affine_act_backward2_f32(
+                    dy.data_ptr(), dy2.data_ptr(), 0 if y is None else y.data_ptr(), scale.data_ptr(), dy.numel(),
+                    C, inner, int(ctx.relu), dx.data_ptr(), 0 if dres is None else dres.data_ptr(),
+                    _native.current_stream_ptr(dy.device))
         _native.check(rc, "affine_act_backward")
-        return dx, None, None, dres, None
+        return dx, None, None, dres, None, None
 
 
 def frozen_bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
-                  residual: torch.Tensor = None, relu: bool = True) -> torch.Tensor:
+                  residual: torch.Tensor = None, relu: bool = True, twice: bool = False):
     """Frozen batch-norm as a per-channel affine, optional residual add, optional ReLU.
     Device float32 NCHW tensors take the fused HIP kernel; anything else evaluates the
-    reference's own formula (backbone.py:62-72) op by op."""
+    reference's own formula (backbone.py:62-72) op by op.
+    twice: return (y, y') -- two handles on the result for its two consumers, whose gradients the backward
+    kernel adds on the fly (only with the fused kernel and a gradient to compute; else (y, y))."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
-        return _AffineAct.apply(x, scale.contiguous(), shift.contiguous(), residual, relu)
+        if twice and FAN_OUT and torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
+            return _AffineAct.apply(x, scale.contiguous(), shift.contiguous(), residual, relu, True)
+        y = _AffineAct.apply(x, scale.contiguous(), shift.contiguous(), residual, relu)
+        return (y, y) if twice else y
     y = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if residual is not None:
         y = y + residual
-    return torch.relu(y) if relu else y
+    y = torch.relu(y) if relu else y
+    return (y, y) if twice else y
 
 
 class _GroupNormNHWC(Function):

@@ -209,6 +209,12 @@ int datr_affine_act_forward_f32(const float *x, const float *res, const float *s
 int datr_affine_act_backward_f32(const float *dy, const float *y, const float *scale, int64_t n,
                                  int64_t C, int64_t inner, int relu, float *dx, float *dres,
                                  void *stream);
+/* The same with TWO upstream gradients (g = (dy + dy2) * ...): a bottleneck's output feeds the next
+ * bottleneck's conv1 AND its identity branch (torchvision Bottleneck.forward); summing the two gradients
+ * here costs one extra read instead of autograd's separate three-pass add. */
+int datr_affine_act_backward2_f32(const float *dy, const float *dy2, const float *y, const float *scale,
+                                  int64_t n, int64_t C, int64_t inner, int relu, float *dx, float *dres,
+                                  void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution, NCHW fp32, exact-fp32 MFMA implicit GEMM, with fused

@@ -538,3 +538,34 @@ def test_fan_out_passes_through_without_gradient():
     x = torch.randn(5, 3, device="cuda:0")
     a, b = fan_out(x, 2)
     assert a is x and b is x
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_frozen_bn_act_two_handles_sum_their_gradients_in_the_kernel(nhwc, with_res):
+    """frozen_bn_act(..., twice=True): the output as two handles (next bottleneck's conv1 + identity branch,
+    torchvision Bottleneck.forward); datr_affine_act_backward2_f32 adds their gradients on the fly -- same
+    result as one handle used twice."""
+    from datr_amd.fused import frozen_bn_act
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    fmt = torch.channels_last if nhwc else torch.contiguous_format
+    x0 = torch.randn(2, 64, 9, 11, generator=g).to(dev).contiguous(memory_format=fmt)
+    r0 = torch.randn(2, 64, 9, 11, generator=g).to(dev).contiguous(memory_format=fmt)
+    scale = (torch.rand(64, generator=g) + 0.5).to(dev)
+    shift = torch.randn(64, generator=g).to(dev)
+    wa, wb = (torch.randn(2, 64, 9, 11, generator=g).to(dev) for _ in range(2))
+
+    def run(twice):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(with_res)
+        out = frozen_bn_act(x, scale, shift, residual=r if with_res else None, relu=True, twice=twice)
+        a, b = out if twice else (out, out)
+        ((a * wa).sum() + (b * wb).sum()).backward()
+        return a.detach(), x.grad, (r.grad if with_res else None)
+
+    y1, gx1, gr1 = run(False)
+    y2, gx2, gr2 = run(True)
+    assert torch.equal(y1, y2)
+    torch.testing.assert_close(gx1, gx2, rtol=1e-6, atol=1e-6)
+    if with_res:
+        torch.testing.assert_close(gr1, gr2, rtol=1e-6, atol=1e-6)
