@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .fused import frozen_bn_act
+from .fused import fan_out, frozen_bn_act
 from . import strided
 from .wino import conv3x3_bn_relu, conv3x3_own_wgrad
 from . import pointwise
@@ -110,11 +110,11 @@ class Bottleneck(nn.Module):
             if nhwc and folded is not None and folded[1] is not None:
                 shift_ds = self.downsample[1].scale_shift()[1]
                 if ds_conv.stride == (1, 1):
-                    identity = pointwise.conv1x1(x, folded[1], shift_ds)
+                    identity = pointwise.conv1x1(x_id, folded[1], shift_ds)
                 elif ds_conv.stride == (2, 2):           # even pixels gathered, then the same GEMM
-                    identity = strided.conv1x1_s2(x, folded[1], shift_ds)
+                    identity = strided.conv1x1_s2(x_id, folded[1], shift_ds)
             if identity is None:
-                identity = frozen_bn_act(ds_conv(x), *self.downsample[1].scale_shift(), relu=False)
+                identity = frozen_bn_act(ds_conv(x_id), *self.downsample[1].scale_shift(), relu=False)
         out = None
         if nhwc and folded is not None:
             out = pointwise.conv1x1(x, folded[0], self.bn1.scale_shift()[1], relu=True)
@@ -249,7 +249,15 @@ class _StageOutputs(nn.ModuleDict):
                 continue
             x = child(x)
             if name in self.return_layers:
-                out[self.return_layers[name]] = x
+                # a returned stage output has three kinds of consumers: the next stage's conv1, its
+                # downsample branch, and the neck / discriminator -- one handle each, their gradients
+                # meet in one pass (fused.fan_out) instead of pairwise adds over the feature map
+                if i + 1 < len(items) and self.training and isinstance(x, torch.Tensor):
+                    h = fan_out(x, 3)
+                    out[self.return_layers[name]] = h[2]
+                    x = (h[0], h[1]) if h[0] is not h[1] else x
+                else:
+                    out[self.return_layers[name]] = x
             i += 1
         return out
 
