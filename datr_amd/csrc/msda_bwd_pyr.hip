@@ -129,6 +129,9 @@ struct Sample {
     int row;           // window row index of the top-left corner (when bit 4)
 };
 
+// kDots = false: grad_loc / grad_attn come from msda_fwd_pyr2.hip's LDS-window kernel
+// (msda_bwd_dots_pyr2_d32); this kernel then reads no value rows at all.
+template <bool kDots>
 __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, const PyrMeta pm, int S, int M,
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
 #undef DATR_DIRECT
             }
 
+            if constexpr (kDots) {
             // corner offsets of this lane's sample (out-of-image corners read zeros)
             int g[4];
             g[0] = (int)((s.flags & 1) ? pix : kOutOfRange);
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
                 const size_t idx = (((size_t)n * Lq + qtab[qslot]) * M + m) * 16 + l * 4 + j;
                 grad_attn[idx] = pa;
                 reinterpret_cast<f2 *>(grad_loc)[idx] = f2{pw * s.a * Wf, ph * s.a * Hf};
+            }
             }
         }
         TICK(3);                               // pass B: records, gathers, dots
@@ -440,6 +445,11 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
 }
 
 }  // namespace
+
+extern "C" int datr_internal_msda_bwd_dots_pyr2_d32(
+    const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
+    const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream);
 
 // Region plan of the backward kernel; false when the shape is not covered.
 // `envelope_host` ([8 heads][4 levels]{oy_lo, oy_hi, ox_lo, ox_hi} in pixels of the sampled level, or
@@ -534,18 +544,37 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
 {
     PyrMeta pm;
     if (!bwd_pyr_plan(pm, shapes_host, level_start_host, N, S, M, D, L, Lq, P, envelope_host)) return DATR_EUNSUPPORTED;
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32),
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32<true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    kLdsBytes) == hipSuccess &&
+                                hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32<false>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     kLdsBytes) == hipSuccess;
     if (!attr_ok) return DATR_EUNSUPPORTED;
+    // grad_loc / grad_attn out of LDS windows by the forward's structure where its plan covers the shape
+    // (DATR_MSDA_BWD_SPLIT=0: this kernel's own gathers, for A/B measurements)
+    static const bool split = !(getenv("DATR_MSDA_BWD_SPLIT") && atoi(getenv("DATR_MSDA_BWD_SPLIT")) == 0);
+    bool dots_done = false;
+    if (split) {
+        const int rc = datr_internal_msda_bwd_dots_pyr2_d32(grad_out, value, loc, attn, shapes_host, level_start_host,
+                                                            envelope_host, N, S, M, D, L, Lq, P, grad_loc, grad_attn,
+                                                            stream);
+        if (rc == DATR_OK) dots_done = true;
+        else if (rc != DATR_EUNSUPPORTED) return rc;
+    }
 #if PYRB_BANDS
     const long blocks = (long)N * ((pm.nRy * pm.nRx + 7) / 8) * 8 * M;
 #else
     const long blocks = (long)N * pm.nRy * pm.nRx * M;
 #endif
     if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
-    hipLaunchKernelGGL(msda_bwd_pyr_d32, dim3((unsigned)blocks), dim3(kThreads), (size_t)kLdsBytes,
-                       (hipStream_t)stream, grad_out, value, loc, attn, pm, (int)S, (int)M, grad_value,
-                       grad_loc, grad_attn);
+    if (dots_done)
+        hipLaunchKernelGGL(msda_bwd_pyr_d32<false>, dim3((unsigned)blocks), dim3(kThreads), (size_t)kLdsBytes,
+                           (hipStream_t)stream, grad_out, value, loc, attn, pm, (int)S, (int)M, grad_value,
+                           grad_loc, grad_attn);
+    else
+        hipLaunchKernelGGL(msda_bwd_pyr_d32<true>, dim3((unsigned)blocks), dim3(kThreads), (size_t)kLdsBytes,
+                           (hipStream_t)stream, grad_out, value, loc, attn, pm, (int)S, (int)M, grad_value,
+                           grad_loc, grad_attn);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }

@@ -47,7 +47,8 @@
 
 // Development only: compile pieces out to see what they cost (results are wrong with a bit set).
 // 1 = no window fill, 4 = no LDS gathers, 8 = no loc/attn loads, 16 = no output stores, 32 = no blend FMAs,
-// 64 = no level loop at all (launch + prologue only), 128 = no barriers
+// 64 = no level loop at all (launch + prologue only), 128 = no barriers; backward (kDots) only: 256 = no
+// grad_loc / grad_attn stores, 512 = no quad sums
 #ifndef PYR2_ABLATE
 #define PYR2_ABLATE 0
 #endif
@@ -222,16 +223,96 @@ __device__ __forceinline__ void corner_weights(float (&w)[4], const Pix &p, floa
     w[3] = al * p.lw;
 }
 
-template <int kTPW, int kCfg>
-__global__ __launch_bounds__(kP2Configs[kCfg].threads, kP2Configs[kCfg].wgs_per_cu * kP2Configs[kCfg].threads / 256)
-void msda_fwd_pyr2_d32(
+// The workgroup's program.  kDots = false: the forward (out = sum of a * bilinear(value)).
+// kDots = true: the value-dependent half of the BACKWARD (cuh:301-403) with the same windows, phases and
+// tasks -- lane j dots the four corner rows of ITS sample (point j of the level) with the query's
+// grad_out row and turns the four dot products into grad_attn = <grad_out, bilinear(value)> and
+// grad_loc = a * {W, H} * <grad_out, d bilinear / d (w, h)>.
+// ---- backward (kDots) ------------------------------------------------------------------------------
+// sum over the 4 lanes of a quad; every lane ends with the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+// Point SRC of the quad's query: the four corner dot products <grad_out, row> (cuh:301-403 sums
+// top_grad * v_k over the channels): packed FMAs over the lane's 8 channels, two DPP steps across the
+// quad.  Lane SRC -- the lane that holds point SRC's geometry -- keeps them in d.
+template <int SRC>
+__device__ __forceinline__ void point_dots(float (&d)[4], const f4 goA, const f4 goB, const Rows &r, const int j) {
+    const f2 a_lo = {goA.x, goA.y}, a_hi = {goA.z, goA.w}, b_lo = {goB.x, goB.y}, b_hi = {goB.z, goB.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f2 acc = f2{r.a[k].x, r.a[k].y} * a_lo;
+        acc = __builtin_elementwise_fma(f2{r.a[k].z, r.a[k].w}, a_hi, acc);
+        acc = __builtin_elementwise_fma(f2{r.b[k].x, r.b[k].y}, b_lo, acc);
+        acc = __builtin_elementwise_fma(f2{r.b[k].z, r.b[k].w}, b_hi, acc);
+        const float s = (PYR2_ABLATE & 512) ? acc.x + acc.y : quad_sum(acc.x + acc.y);
+        d[k] = j == SRC ? s : d[k];
+    }
+}
+// The four points of one level out of the LDS window (the forward's lds_level): lane j leaves with
+// the four dot products of point j.
+template <int kDepth>
+__device__ __forceinline__ void lds_level_dots(float (&d)[4], const f4 goA, const f4 goB, const int base,
+                                               const int j, const int chan, const int row_bytes) {
+    if constexpr (kDepth == 1) {
+        Rows r;
+        fetch_lds<0>(r, base, chan, row_bytes);
+        point_dots<0>(d, goA, goB, r, j);
+        fetch_lds<1>(r, base, chan, row_bytes);
+        point_dots<1>(d, goA, goB, r, j);
+        fetch_lds<2>(r, base, chan, row_bytes);
+        point_dots<2>(d, goA, goB, r, j);
+        fetch_lds<3>(r, base, chan, row_bytes);
+        point_dots<3>(d, goA, goB, r, j);
+    } else {
+        Rows r0, r1;
+        fetch_lds<0>(r0, base, chan, row_bytes);
+        fetch_lds<1>(r1, base, chan, row_bytes);
+        point_dots<0>(d, goA, goB, r0, j);
+        fetch_lds<2>(r0, base, chan, row_bytes);
+        point_dots<1>(d, goA, goB, r1, j);
+        fetch_lds<3>(r1, base, chan, row_bytes);
+        point_dots<2>(d, goA, goB, r0, j);
+        point_dots<3>(d, goA, goB, r1, j);
+    }
+}
+// 4 x 4 transpose across the lanes of a quad: lane j enters with v[i] = M[j][i] and leaves with M[i][j]
+__device__ __forceinline__ void quad_transpose(float (&v)[4], const int j) {
+    const bool b0 = j & 1, b1 = j & 2;
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {                 // exchange with lane ^ 1: register pairs (0, 1), (2, 3)
+        const float send = b0 ? v[q] : v[q + 1];
+        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+        if (b0) v[q] = recv; else v[q + 1] = recv;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                    // exchange with lane ^ 2: register pairs (0, 2), (1, 3)
+        const float send = b1 ? v[q] : v[q + 2];
+        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+        if (b1) v[q] = recv; else v[q + 2] = recv;
+    }
+}
+// cuh:301-403 for one sample: pa = <grad_out, bilinear(value)>, pw / ph = its derivatives in lw / lh
+__device__ __forceinline__ void combine_dots(float &pa, float &pw, float &ph, const float (&d)[4], const Pix &p) {
+    const float hh = 1.f - p.lh, hw = 1.f - p.lw;
+    pa = hh * hw * d[0] + hh * p.lw * d[1] + p.lh * hw * d[2] + p.lh * p.lw * d[3];
+    pw = hh * (d[1] - d[0]) + p.lh * (d[3] - d[2]);
+    ph = hw * (d[2] - d[0]) + p.lw * (d[3] - d[1]);
+}
+
+template <int kTPW, int kCfg, bool kDots>
+__device__ __forceinline__ void pyr2_body(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
-    const Pyr2Meta pm, int S, int M, int nimg, float *__restrict__ out)
+    const Pyr2Meta &pm, int S, int M, int nimg, float *__restrict__ out,
+    const float *__restrict__ grad_out, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int kP2Threads = kP2Configs[kCfg].threads, kP2Waves = kP2Threads / 64;
     // two samples' corner rows in flight where the register budget allows (168 VGPRs at 3 x 256 threads)
-    constexpr int kDepth = (kCfg == 1 || kTPW <= 2) ? 2 : 1;
+    // (the backward holds 12 results per task until its last level: one sample in flight at 128 VGPRs)
+    constexpr int kDepth = kDots ? (kCfg == 1 ? 2 : 1) : (kCfg == 1 || kTPW <= 2) ? 2 : 1;
     const int tid = threadIdx.x;
     const int nreg = pm.nRy * pm.nRx;
     const unsigned row_stride = (unsigned)M * kRowBytes;           // bytes between pixels of one head
@@ -347,7 +428,7 @@ void msda_fwd_pyr2_d32(
     int soff[kTPW];                                                // first sample index of the task's (query, head)
 #pragma unroll
     for (int t = 0; t < kTPW; ++t) {
-        accA[t] = accB[t] = f4{0.f, 0.f, 0.f, 0.f};
+        accA[t] = accB[t] = f4{0.f, 0.f, 0.f, 0.f};                 // kDots: the grad_out pieces (below)
         int qi = (wave + t * kP2Waves) * 16 + slot;
         qi = qi < nq ? qi : nq - 1;
         const int lq = (qi >= pre[1]) + (qi >= pre[2]) + (qi >= pre[3]);
@@ -360,6 +441,11 @@ void msda_fwd_pyr2_d32(
         const int r_ = (int)(((float)li + 0.5f) / (float)rw);
         const int q = sq + (oy + r_) * Wq + ox + (li - r_ * rw);
         soff[t] = ((n * S + q) * M + m) * 16;
+        if constexpr (kDots) {                                     // the query's grad_out row (this head)
+            const float *src = grad_out + (size_t)soff[t] * 2;
+            accA[t] = *reinterpret_cast<const f4 *>(src + (chan >> 2));
+            accB[t] = *reinterpret_cast<const f4 *>(src + ((chan ^ 64) >> 2));
+        }
     }
     struct LocW { f2 xy; float a; };
     auto load_sample = [&](int so, int l) {
@@ -382,6 +468,7 @@ void msda_fwd_pyr2_d32(
     // Memory-level parallelism: a level's locations / weights of ALL of the wave's tasks are
     // requested one level ahead (4 x 768 B per wave, ~36 KB per CU in flight).
     LocW cur[kTPW], nxt[kTPW];
+    float res_a[kDots ? kTPW : 1][4], res_w[kDots ? kTPW : 1][4], res_h[kDots ? kTPW : 1][4];   // kDots: [task][level]
     auto load_level = [&](LocW (&dst)[kTPW], int l) {
 #pragma unroll
         for (int t = 0; t < kTPW; ++t)
@@ -432,8 +519,51 @@ void msda_fwd_pyr2_d32(
             const bool miss = p.inside && !inwin;
             const int wb = lbase + ((inwin ? wy : 0) * WW + (inwin ? wx : 0)) * kRowBytes;
             float w[4];
-            corner_weights(w, p, use ? cur[t].a : 0.f);
-            lds_level<kDepth>(accA[t], accB[t], wb, w, chan, row_bytes);
+            if constexpr (kDots) {
+                float d[4] = {0.f, 0.f, 0.f, 0.f};                 // the corner dot products of THIS lane's sample
+                lds_level_dots<kDepth>(d, accA[t], accB[t], wb, j, chan, row_bytes);
+                if (__builtin_amdgcn_ballot_w64(miss) != 0) {      // rare: rows from global memory
+                    const int stl = lv[l].start;
+                    const bool top = p.iy >= 0, bot = p.iy + 1 <= Hl - 1, lef = p.ix >= 0, rig = p.ix + 1 <= Wl - 1;
+                    const unsigned pix = (unsigned)(stl + p.iy * Wl + p.ix) * row_stride;
+                    int g[4];
+                    g[0] = (int)((miss && top && lef) ? pix : kOutOfRange);
+                    g[1] = (int)((miss && top && rig) ? pix + row_stride : kOutOfRange);
+                    g[2] = (int)((miss && bot && lef) ? pix + (unsigned)Wl * row_stride : kOutOfRange);
+                    g[3] = (int)((miss && bot && rig) ? pix + (unsigned)(Wl + 1) * row_stride : kOutOfRange);
+                    auto one = [&](int flag, auto src) {
+                        constexpr int SRC = decltype(src)::value;
+                        if (flag) {                                // the quads whose sample SRC missed
+                            Rows r;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const unsigned o = (unsigned)quad_bcast<SRC>(g[k]);
+                                r.a[k] = load_row4(rsrc, o + (unsigned)chan);
+                                r.b[k] = load_row4(rsrc, o + (unsigned)(chan ^ 64));
+                            }
+                            point_dots<SRC>(d, accA[t], accB[t], r, j);
+                        }
+                    };
+                    const int mi = miss ? 1 : 0;
+                    one(quad_bcast<0>(mi), std::integral_constant<int, 0>{});
+                    one(quad_bcast<1>(mi), std::integral_constant<int, 1>{});
+                    one(quad_bcast<2>(mi), std::integral_constant<int, 2>{});
+                    one(quad_bcast<3>(mi), std::integral_constant<int, 3>{});
+                }
+                float pa = 0.f, pw = 0.f, ph = 0.f;
+                if (p.inside) combine_dots(pa, pw, ph, d, p);
+                // kept until all four levels are done: written per level, the 16-B / 32-B pieces of a
+                // (query, head)'s 64-B / 128-B gradient rows cost 72 of the kernel's 194 us
+                res_a[t][l] = pa;
+                res_w[t][l] = pw * cur[t].a * (float)Wl;
+                res_h[t][l] = ph * cur[t].a * (float)Hl;
+                PIN(accA[t], accB[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            } else {
+                corner_weights(w, p, use ? cur[t].a : 0.f);
+                lds_level<kDepth>(accA[t], accB[t], wb, w, chan, row_bytes);
+            }
 
             // ---- slow path (rare): samples outside their window come from global memory ----------
             if (__builtin_amdgcn_ballot_w64(miss) != 0) {
@@ -478,6 +608,33 @@ void msda_fwd_pyr2_d32(
     }
 
     // ---- output rows ---------------------------------------------------------------------------
+    if constexpr (kDots) {
+        // lane j holds point j of levels 0..3; a 4 x 4 transpose inside the quad leaves it with the four
+        // points of LEVEL j: one 16-B store of grad_attn, two of grad_loc; a quad writes whole rows
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) {
+            const int ti = wave + t * kP2Waves;
+            if (ti >= ntasks) break;
+            quad_transpose(res_a[t], j);
+            quad_transpose(res_w[t], j);
+            quad_transpose(res_h[t], j);
+            if (ti * 16 + slot < nq && (!(PYR2_ABLATE & 256) || res_a[t][0] == 123.456f)) {
+                const int idx = soff[t] + 4 * j;
+                f4 *gl = reinterpret_cast<f4 *>(grad_loc + (size_t)idx * 2);
+#if PYR2_OUT_NT
+                __builtin_nontemporal_store(f4{res_a[t][0], res_a[t][1], res_a[t][2], res_a[t][3]},
+                                            reinterpret_cast<f4 *>(grad_attn + idx));
+                __builtin_nontemporal_store(f4{res_w[t][0], res_h[t][0], res_w[t][1], res_h[t][1]}, gl);
+                __builtin_nontemporal_store(f4{res_w[t][2], res_h[t][2], res_w[t][3], res_h[t][3]}, gl + 1);
+#else
+                *reinterpret_cast<f4 *>(grad_attn + idx) = f4{res_a[t][0], res_a[t][1], res_a[t][2], res_a[t][3]};
+                gl[0] = f4{res_w[t][0], res_h[t][0], res_w[t][1], res_h[t][1]};
+                gl[1] = f4{res_w[t][2], res_h[t][2], res_w[t][3], res_h[t][3]};
+#endif
+            }
+        }
+    }
+    if constexpr (!kDots)
 #pragma unroll
     for (int t = 0; t < kTPW; ++t) {
         const int ti = wave + t * kP2Waves;
@@ -511,6 +668,48 @@ void msda_fwd_pyr2_d32(
         pyr2_wg_span[blockIdx.x][3] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
     }
 #endif
+}
+
+template <int kTPW, int kCfg>
+__global__ __launch_bounds__(kP2Configs[kCfg].threads, kP2Configs[kCfg].wgs_per_cu * kP2Configs[kCfg].threads / 256)
+void msda_fwd_pyr2_d32(
+    const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
+    const Pyr2Meta pm, int S, int M, int nimg, float *__restrict__ out)
+{
+    pyr2_body<kTPW, kCfg, false>(value, loc, attn, pm, S, M, nimg, out, nullptr, nullptr, nullptr);
+}
+
+// grad_loc / grad_attn of the encoder calls (the value-dependent half of the backward; grad_value is
+// msda_bwd_pyr.hip's sorted scatter, which needs no value rows)
+template <int kTPW, int kCfg>
+__global__ __launch_bounds__(kP2Configs[kCfg].threads, kP2Configs[kCfg].wgs_per_cu * kP2Configs[kCfg].threads / 256)
+void msda_bwd_dots_pyr2_d32(
+    const float *__restrict__ grad_out, const float *__restrict__ value, const float *__restrict__ loc,
+    const float *__restrict__ attn, const Pyr2Meta pm, int S, int M, int nimg,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+{
+    pyr2_body<kTPW, kCfg, true>(value, loc, attn, pm, S, M, nimg, nullptr, grad_out, grad_loc, grad_attn);
+}
+
+template <int kTPW, int kCfg>
+int launch_dots(const float *grad_out, const float *value, const float *loc, const float *attn,
+                const Pyr2Meta &pm, int64_t N, int64_t S, int64_t M, float *grad_loc, float *grad_attn,
+                hipStream_t stream) {
+    constexpr Pyr2Config cfg = kP2Configs[kCfg];
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_dots_pyr2_d32<kTPW, kCfg>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    p2_lds_bytes(cfg)) == hipSuccess;
+    if (!attr_ok) return DATR_EUNSUPPORTED;
+#if PYR2_BANDS
+    const long blocks = ((long)N * pm.nRy * pm.nRx + 7) / 8 * 8 * M;
+#else
+    const long blocks = (long)N * pm.nRy * pm.nRx * M;
+#endif
+    if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
+    hipLaunchKernelGGL((msda_bwd_dots_pyr2_d32<kTPW, kCfg>), dim3((unsigned)blocks), dim3(cfg.threads),
+                       (size_t)p2_window_rows(cfg) * kRowBytes, stream, grad_out, value, loc, attn, pm, (int)S,
+                       (int)M, (int)N, grad_loc, grad_attn);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 
 template <int kTPW, int kCfg>
@@ -628,4 +827,29 @@ extern "C" int datr_internal_msda_fwd_pyr2_d32(
     hipStream_t st = (hipStream_t)stream;
     return pm.config == 1 ? launch_tpw<1>(value, loc, attn, pm, N, S, M, out, st)
                           : launch_tpw<0>(value, loc, attn, pm, N, S, M, out, st);
+}
+
+// The value-dependent half of the encoder backward: grad_loc / grad_attn (every element written).
+// DATR_EUNSUPPORTED when the forward's plan does not cover the shape (the caller then lets
+// msda_bwd_pyr.hip compute them with its own gathers).
+extern "C" int datr_internal_msda_bwd_dots_pyr2_d32(
+    const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
+    const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream)
+{
+    if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || M > kP2Heads || N < 1) return DATR_EUNSUPPORTED;
+    if (N * S * M * 128 >= (1LL << 31)) return DATR_EUNSUPPORTED;
+    Pyr2Meta pm;
+    const int rc = datr_internal_msda_fwd_pyr2_plan(shapes_host, level_start_host, S, M, envelope_host, &pm, nullptr);
+    if (rc != DATR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const auto go = [&](auto cfg) -> int {
+        constexpr int kCfg = decltype(cfg)::value;
+        switch (pm.tpw) {
+            case 1: case 2: return launch_dots<2, kCfg>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
+            case 3: return launch_dots<3, kCfg>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
+            default: return DATR_EUNSUPPORTED;
+        }
+    };
+    return pm.config == 1 ? go(std::integral_constant<int, 1>{}) : go(std::integral_constant<int, 0>{});
 }
