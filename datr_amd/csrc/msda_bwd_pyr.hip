@@ -9,8 +9,8 @@
 // fixed-point ds_add_u64: 728 M lane-adds per N=4 encoder call at 2.45 lane-ops/clk/CU are half
 // of its 0.97 ms (profiles/r01_probes.md), and its 16 x 8 tiles flush 14.6 window rows per query
 // with float atomics (2.8-3.8x the algorithmic write traffic).  Here:
-//   * a 768-thread workgroup owns one (image, region, head): all queries of a region of about
-//     12 x 28 level-0 pixels in all four levels (<= 512 queries), i.e. 4 window rows per query;
+//   * a workgroup (256 threads / <= 128 queries, or 512 / <= 256 where the samples reach far: BCfg
+//     below) owns one (image, region, head): all queries of a region in all four levels;
 //   * per level the 16 corner contributions of every query are written as 8-byte records
 //     {weight = corner weight x attention, query slot} into LDS, COUNTING-SORTED by destination
 //     row of the level's window: one 32-bit LDS atomic per record for the histogram and one for
@@ -19,10 +19,11 @@
 //     accumulate weight x grad_out[slot] in registers from the workgroup's LDS copy of its
 //     queries' grad_out rows (ds_read_b128, no atomics), and add the finished row to grad_value
 //     with one 128-byte-coalesced float atomic pass (windows of neighbouring regions overlap);
-//   * grad_attn / grad_loc come from the corner rows gathered with zero-filling buffer loads
-//     as before; lane roles as in msda_fwd_pyr.hip: 4 lanes share a query, lane p works out
-//     point p's geometry, a quad covers a 128-B row with two 64-B halves, dot products are
-//     completed with two DPP steps inside the quad.
+//   * grad_attn / grad_loc -- the value-dependent half -- come from msda_fwd_pyr2.hip's LDS-window
+//     kernel (msda_bwd_dots_pyr2_d32) where the forward's plan covers the shape, and this kernel reads
+//     no value rows (kDots = false); otherwise (kDots = true) from the corner rows gathered here with
+//     zero-filling buffer loads: 4 lanes share a query, lane p works out point p's geometry, a quad
+//     covers a 128-B row with two 64-B halves, dot products are completed with two DPP steps.
 // A sample whose corners fall outside the level's window (offsets beyond the halo) bypasses the
 // sort: its contributions go to grad_value as plain float atomics -- results never depend on
 // the window heuristic.  grad_value must arrive zero-filled (the C entry point memsets it).
@@ -33,6 +34,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "datr_hip.h"
 #include "msda_pyr.h"
@@ -66,33 +68,38 @@ namespace {
 #ifndef PYRB_BANDS
 #define PYRB_BANDS 0
 #endif
-#ifndef PYRB_THREADS
-#define PYRB_THREADS 512
-#endif
-#ifndef PYRB_MAXQ
-#define PYRB_MAXQ 256
-#endif
-constexpr int kThreads = PYRB_THREADS;
-constexpr int kWaves = kThreads / 64;
-constexpr int kMaxQ = PYRB_MAXQ;           // queries of a region
 constexpr int kMaxRows = 1024;             // rows of a level's window
-constexpr int kMaxTasks = (kMaxQ / 16 + kWaves - 1) / kWaves;      // 16-query tasks per wave: 3
 constexpr unsigned kOutOfRange = 0x80000000u;
 constexpr int kRowBytes = 128;
 constexpr int kInFlight = PYRB_INFLIGHT;    // records of a row in flight in the reduce phase
 
-// LDS map (bytes)
-constexpr int kGoOff = 0;                                  // grad_out rows by query slot
-constexpr int kRecOff = kGoOff + kMaxQ * kRowBytes;        // records of the current level
-constexpr int kHistOff = kRecOff + kMaxQ * 16 * 8;         // counts -> exclusive offsets [rows + 1]
-constexpr int kCurOff = kHistOff + (2 * kThreads) * 4;     // cursors (pass B); in the reduce phase: flush scratch
-constexpr int kFlushPerWave = 8 * kRowBytes + 8 * 4;       // 8 finished rows + their global offsets
-constexpr int kCurBytes = (2 * kThreads) * 4 > kWaves * kFlushPerWave ? (2 * kThreads) * 4 : kWaves * kFlushPerWave;
-constexpr int kTabOff = kCurOff + ((kCurBytes + 15) & ~15);   // query slot -> pyramid index
-constexpr int kScanOff = kTabOff + kMaxQ * 4;              // per-wave totals of the scan
-constexpr int kLdsBytes = kScanOff + 64;
-static_assert(kMaxRows + 1 <= 2 * kThreads || true, "the scan gives every thread two histogram entries");
-static_assert(kLdsBytes <= 160 * 1024, "LDS");
+// Launch shape: threads per workgroup and the most queries a region may hold.  256 / 128 since the value
+// gathers left the kernel (tools/probes/bwd_scatter_cfgs.sh: 372 us per N = 4 encoder call at the model's
+// offsets; 512 / 256: 400, 768 / 384: 603, 1024 / 512: 449 us); 512 / 256 where the sample reach makes
+// the windows of 128-query regions too large (offsets ~ N(0, 2.5 px): 718 against 943 us).
+template <int THREADS, int MAXQ>
+struct BCfg {
+    static constexpr int kThreads = THREADS, kWaves = THREADS / 64, kMaxQ = MAXQ;
+    static constexpr int kMaxTasks = (kMaxQ / 16 + kWaves - 1) / kWaves;      // 16-query tasks per wave
+    // LDS map (bytes)
+    static constexpr int kGoOff = 0;                                  // grad_out rows by query slot
+    static constexpr int kRecOff = kGoOff + kMaxQ * kRowBytes;        // records of the current level
+    static constexpr int kHistOff = kRecOff + kMaxQ * 16 * 8;         // counts -> exclusive offsets [rows + 1]
+    static constexpr int kCurOff = kHistOff + (2 * kThreads) * 4;     // cursors (pass B); in the reduce phase: flush scratch
+    static constexpr int kFlushPerWave = 8 * kRowBytes + 8 * 4;       // 8 finished rows + their global offsets
+    static constexpr int kCurBytes = (2 * kThreads) * 4 > kWaves * kFlushPerWave ? (2 * kThreads) * 4 : kWaves * kFlushPerWave;
+    static constexpr int kTabOff = kCurOff + ((kCurBytes + 15) & ~15);   // query slot -> pyramid index
+    static constexpr int kScanOff = kTabOff + kMaxQ * 4;              // per-wave totals of the scan
+    static constexpr int kLdsBytes = kScanOff + 64;
+    static_assert(kLdsBytes <= 160 * 1024, "LDS");
+};
+#ifdef PYRB_THREADS
+typedef BCfg<PYRB_THREADS, PYRB_MAXQ> CfgSmall;                     // development: one forced shape
+typedef BCfg<PYRB_THREADS, PYRB_MAXQ> CfgLarge;
+#else
+typedef BCfg<256, 128> CfgSmall;
+typedef BCfg<512, 256> CfgLarge;
+#endif
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -131,12 +138,15 @@ struct Sample {
 
 // kDots = false: grad_loc / grad_attn come from msda_fwd_pyr2.hip's LDS-window kernel
 // (msda_bwd_dots_pyr2_d32); this kernel then reads no value rows at all.
-template <bool kDots>
-__global__ __launch_bounds__(kThreads) void msda_bwd_pyr_d32(
+template <class C, bool kDots>
+__global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, const PyrMeta pm, int S, int M,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
 {
+    constexpr int kThreads = C::kThreads, kWaves = C::kWaves, kMaxTasks = C::kMaxTasks, kGoOff = C::kGoOff,
+                  kRecOff = C::kRecOff, kHistOff = C::kHistOff, kCurOff = C::kCurOff, kFlushPerWave = C::kFlushPerWave,
+                  kTabOff = C::kTabOff, kScanOff = C::kScanOff;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     unsigned *hist = reinterpret_cast<unsigned *>(lds + kHistOff);
     unsigned *cur = reinterpret_cast<unsigned *>(lds + kCurOff);
@@ -457,12 +467,15 @@ extern "C" int datr_internal_msda_bwd_dots_pyr2_d32(
 // envelope).  With it the windows are exactly as wide as the samples reach; without it they are made as
 // wide as the 1024-row histogram allows.  Either way a sample outside its window takes the direct-atomic
 // path: results never depend on it.
+// `small` (out): the plan is for the 256-thread / 128-query launch shape.
 static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t *level_start_host,
                          int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
-                         const float *envelope_host = nullptr) {
+                         const float *envelope_host = nullptr, bool *small = nullptr) {
     if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || N < 1) return false;
     static const float halo = pyr_halo_from_env();
-    const auto fits = [](const PyrMeta &m_, int most_queries) {
+    if (small) *small = false;
+    int kThreads = CfgLarge::kThreads, kMaxQ = CfgLarge::kMaxQ;
+    const auto fits = [&](const PyrMeta &m_, int most_queries) {
         int rows = 0;
         for (int l = 0; l < 4; ++l) rows = std::max(rows, m_.WH[l] * m_.WW[l]);
         return rows <= kMaxRows && rows + 1 <= 2 * kThreads && most_queries <= kMaxQ;
@@ -485,6 +498,14 @@ static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t 
                 }
             h4[l] = std::min(std::max(r + kEnvelopeMargin, 1.0f), 12.0f);
         }
+        // the small launch shape while the reach is short: its 128-query regions carry the halo of a
+        // region twice the size
+        static const float small_reach = getenv("DATR_MSDA_PYRB_SMALL_REACH") ? (float)atof(getenv("DATR_MSDA_PYRB_SMALL_REACH")) : 6.0f;
+        const float reach = std::max(std::max(h4[0], h4[1]), std::max(h4[2], h4[3]));
+        if (sane && reach <= small_reach) {
+            kThreads = CfgSmall::kThreads; kMaxQ = CfgSmall::kMaxQ;
+            if (small) *small = true;
+        }
         if (sane && build_pyr_meta(pm, shapes_host, level_start_host, S, h4, kMaxQ >= 512 ? 12.5 : 10.0,
                                    kMaxQ >= 512 ? 28.0 : 16.7, fits)) {
             // A head looks in one direction (the ring initialisation of ms_deform_attn.py:59-68): trim the
@@ -503,6 +524,8 @@ static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t 
                 }
             return true;
         }
+        kThreads = CfgLarge::kThreads; kMaxQ = CfgLarge::kMaxQ;
+        if (small) *small = false;
     }
     if (!build_pyr_meta(pm, shapes_host, level_start_host, S, halo, kMaxQ >= 512 ? 12.5 : 10.0,
                         kMaxQ >= 512 ? 28.0 : 16.7, fits))
@@ -543,14 +566,8 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
     float *grad_loc, float *grad_attn, void *stream)
 {
     PyrMeta pm;
-    if (!bwd_pyr_plan(pm, shapes_host, level_start_host, N, S, M, D, L, Lq, P, envelope_host)) return DATR_EUNSUPPORTED;
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32<true>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    kLdsBytes) == hipSuccess &&
-                                hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32<false>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    kLdsBytes) == hipSuccess;
-    if (!attr_ok) return DATR_EUNSUPPORTED;
+    bool small = false;
+    if (!bwd_pyr_plan(pm, shapes_host, level_start_host, N, S, M, D, L, Lq, P, envelope_host, &small)) return DATR_EUNSUPPORTED;
     // grad_loc / grad_attn out of LDS windows by the forward's structure where its plan covers the shape
     // (DATR_MSDA_BWD_SPLIT=0: this kernel's own gathers, for A/B measurements)
     static const bool split = !(getenv("DATR_MSDA_BWD_SPLIT") && atoi(getenv("DATR_MSDA_BWD_SPLIT")) == 0);
@@ -568,13 +585,18 @@ extern "C" int datr_internal_msda_bwd_pyr_d32(
     const long blocks = (long)N * pm.nRy * pm.nRx * M;
 #endif
     if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
-    if (dots_done)
-        hipLaunchKernelGGL(msda_bwd_pyr_d32<false>, dim3((unsigned)blocks), dim3(kThreads), (size_t)kLdsBytes,
+    const auto launch = [&](auto cfg, auto dots) -> int {
+        using C = decltype(cfg);
+        constexpr bool kDots = decltype(dots)::value;
+        static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_pyr_d32<C, kDots>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        C::kLdsBytes) == hipSuccess;
+        if (!attr_ok) return DATR_EUNSUPPORTED;
+        hipLaunchKernelGGL((msda_bwd_pyr_d32<C, kDots>), dim3((unsigned)blocks), dim3(C::kThreads), (size_t)C::kLdsBytes,
                            (hipStream_t)stream, grad_out, value, loc, attn, pm, (int)S, (int)M, grad_value,
                            grad_loc, grad_attn);
-    else
-        hipLaunchKernelGGL(msda_bwd_pyr_d32<true>, dim3((unsigned)blocks), dim3(kThreads), (size_t)kLdsBytes,
-                           (hipStream_t)stream, grad_out, value, loc, attn, pm, (int)S, (int)M, grad_value,
-                           grad_loc, grad_attn);
-    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+        return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+    };
+    if (small) return dots_done ? launch(CfgSmall{}, std::false_type{}) : launch(CfgSmall{}, std::true_type{});
+    return dots_done ? launch(CfgLarge{}, std::false_type{}) : launch(CfgLarge{}, std::true_type{});
 }
