@@ -32,16 +32,17 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r.get("Counter_Name") != c:
             continue
         k = r["Kernel_Name"]
-        for tag, pat in (("forward", "msda_fwd_pyr"), ("backward", "msda_bwd_pyr")):
+        for tag, pat in (("forward", "msda_fwd_pyr"), ("backward", "msda_bwd_pyr"), ("backward_dots", "msda_bwd_dots")):
             if pat in k:
                 kern.setdefault(tag, {"kernel": (re.search(r"msda_\w+(<\d+>)?", k) or [k])[0]}).setdefault(c + "_KB_per_launch", []).append(float(r["Counter_Value"]))
 fw = kern.get("forward", {})
 out["kernel"] = fw.get("kernel")
 out["FETCH_SIZE_KB_per_launch"] = fw.get("FETCH_SIZE_KB_per_launch", [])
 out["WRITE_SIZE_KB_per_launch"] = fw.get("WRITE_SIZE_KB_per_launch", [])
-out["backward"] = kern.get("backward", {})
+out["backward"] = kern.get("backward", {})            # the sorted scatter (grad_value)
+out["backward_dots"] = kern.get("backward_dots", {})  # grad_loc / grad_attn out of LDS windows
 json.dump(out, open(sys.argv[1], "w"), indent=1)
-for tag in ("forward", "backward"):
+for tag in ("forward", "backward", "backward_dots"):
     k = kern.get(tag, {})
     f_, w_ = k.get("FETCH_SIZE_KB_per_launch", []), k.get("WRITE_SIZE_KB_per_launch", [])
     if f_ and w_:

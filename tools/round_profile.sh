@@ -8,3 +8,4 @@ cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/prof; rocprofv3 --kernel-trace --stat
 cd $GRAFT_REPO_ROOT; f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); python tools/kstats.py $f --steps 4 --marker msda_fwd_pyr2 --per-step 6 --out gpurun_out/r3m/step_kernels.csv --top 90 --split msda_fwd_pyr2 --split-out gpurun_out/r3m/msda_fwd_by_grid.csv 2>&1 | tail -4
 s=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); head -41 $s > gpurun_out/r3m/rocprof_kernel_stats_top40.csv
 bash tools/pmc_step_mfma.sh gpurun_out/r3m/step_mfma.txt > /dev/null 2>&1; tail -3 gpurun_out/r3m/step_mfma.txt
+bash tools/pmc_msda_raw.sh gpurun_out/r3m/msda_pmc.json 2>&1 | tail -3
