@@ -68,6 +68,12 @@ namespace {
 #ifndef PYRB_BANDS
 #define PYRB_BANDS 0
 #endif
+// Development only (results are wrong with a bit set; tools/probes/bwd_scatter_ablate.sh):
+// 1 = no float-atomic flush, 2 = no reduce loop, 4 = no records (pass B), 8 = no histogram atomics (pass A)
+#ifndef PYRB_ABLATE
+#define PYRB_ABLATE 0
+#endif
+
 constexpr int kMaxRows = 1024;             // rows of a level's window
 constexpr unsigned kOutOfRange = 0x80000000u;
 constexpr int kRowBytes = 128;
@@ -259,10 +265,12 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
                     if ((unsigned)wy <= (unsigned)(WH - 2) && (unsigned)wx <= (unsigned)(WW - 2)) {
                         s.flags |= 16;
                         s.row = wy * WW + wx;
+                        if (!(PYRB_ABLATE & 8)) {
                         if (s.flags & 1) atomicAdd(&hist[s.row], 1u);
                         if (s.flags & 2) atomicAdd(&hist[s.row + 1], 1u);
                         if (s.flags & 4) atomicAdd(&hist[s.row + WW], 1u);
                         if (s.flags & 8) atomicAdd(&hist[s.row + WW + 1], 1u);
+                        }
                     }
                 }
             }
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
             const float c0 = hh * hw, c1 = hh * s.lw, c2 = s.lh * hw, c3 = s.lh * s.lw;
             const int iy = s.yx >> 16, ix = (int)(short)(s.yx & 0xffff);
             const unsigned pix = (unsigned)(stl + iy * Wl + ix) * row_stride;
-            if (live && (s.flags & 16)) {
+            if (live && (s.flags & 16) && !(PYRB_ABLATE & 4)) {
                 const unsigned lo = (unsigned)qslot;
 #define DATR_REC(BIT, ROW, C)                                                                    \
                 if (s.flags & (BIT)) {                                                           \
@@ -400,8 +408,10 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
                 if (r < rows) { beg = hist[r]; end = hist[r + 1]; }
                 f4 acc = {0.f, 0.f, 0.f, 0.f};
                 // kInFlight records in flight: record read -> grad_out row read -> FMA is a chain of
-                // two LDS latencies, so the loop is unrolled to keep several chains going
-                for (unsigned e = beg; e < end; e += kInFlight) {
+                // two LDS latencies, so the loop is unrolled to keep several chains going.  Slots past the
+                // row's end re-read its last record with weight 0: guarding the reads instead (exec-masked
+                // ds_read per slot) serialises them -- 497 against 371 us per N = 4 call.
+                for (unsigned e = beg; e < ((PYRB_ABLATE & 2) ? beg : end); e += kInFlight) {
                     unsigned long long rec[kInFlight];
                     f4 g_[kInFlight];
                     float w_[kInFlight];
@@ -438,7 +448,8 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
                     const unsigned o_ = fl_off[g];
                     const float v = *reinterpret_cast<const float *>(fl + g * kRowBytes + l32 * 4);
                     // an empty row has the out-of-range offset: the buffer atomic is dropped
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, gsrc, o_ + (unsigned)l32 * 4u, 0, 0);
+                    if (!(PYRB_ABLATE & 1) || v == 123.456f)
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, gsrc, o_ + (unsigned)l32 * 4u, 0, 0);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();      // the scratch is rewritten by the next round
