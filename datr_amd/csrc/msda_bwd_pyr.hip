@@ -73,6 +73,9 @@ namespace {
 #ifndef PYRB_ABLATE
 #define PYRB_ABLATE 0
 #endif
+#ifndef PYRB_REC_DPP
+#define PYRB_REC_DPP (PYRB_INFLIGHT == 8)
+#endif
 
 constexpr int kMaxRows = 1024;             // rows of a level's window
 constexpr unsigned kOutOfRange = 0x80000000u;
@@ -415,6 +418,34 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
                     unsigned long long rec[kInFlight];
                     f4 g_[kInFlight];
                     float w_[kInFlight];
+#if PYRB_REC_DPP
+                    // ONE record per lane (lane c of the group reads record e + c) handed round the group's 8
+                    // lanes by DPP: a quad broadcast gives a quad its own lane u, the half-row mirror the
+                    // other quad's -- 8 x 64 B of LDS reads per 8 records become 64 B
+                    static_assert(kInFlight == 8, "one record per lane of an 8-lane group");
+                    (void)rec;
+                    const unsigned long long mine = recs[min(e + (unsigned)c8, end - 1)];
+                    const int lo_ = (int)(unsigned)(mine & 0xffffffffull);
+                    const int hi_ = e + (unsigned)c8 < end ? (int)(unsigned)(mine >> 32) : 0;    // weight 0.0f past the end
+                    const bool lower = c8 < 4;
+                    int slot_[8];
+                    auto hand_round = [&](auto uu) {
+                        constexpr int U = decltype(uu)::value;
+                        const int tl = quad_bcast<U>(lo_), th = quad_bcast<U>(hi_);
+                        const int ml = __builtin_amdgcn_update_dpp(0, tl, 0x141, 0xF, 0xF, true);
+                        const int mh = __builtin_amdgcn_update_dpp(0, th, 0x141, 0xF, 0xF, true);
+                        slot_[U] = lower ? tl : ml;      slot_[U + 4] = lower ? ml : tl;
+                        w_[U] = __int_as_float(lower ? th : mh);
+                        w_[U + 4] = __int_as_float(lower ? mh : th);
+                    };
+                    hand_round(std::integral_constant<int, 0>{});
+                    hand_round(std::integral_constant<int, 1>{});
+                    hand_round(std::integral_constant<int, 2>{});
+                    hand_round(std::integral_constant<int, 3>{});
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u)
+                        g_[u] = *reinterpret_cast<const f4 *>(lds + kGoOff + slot_[u] * kRowBytes + c8 * 16);
+#else
 #pragma unroll
                     for (int u = 0; u < kInFlight; ++u) rec[u] = recs[min(e + u, end - 1)];
 #pragma unroll
@@ -423,6 +454,7 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
                         g_[u] = *reinterpret_cast<const f4 *>(
                             lds + kGoOff + (int)(rec[u] & 0xffffffffull) * kRowBytes + c8 * 16);
                     }
+#endif
 #pragma unroll
                     for (int u = 0; u < kInFlight; ++u) {
                         acc.x = fmaf(w_[u], g_[u].x, acc.x);
