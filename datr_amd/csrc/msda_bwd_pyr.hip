@@ -230,6 +230,26 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
     const int chan = 16 * j + 64 * (slot & 1), chan2 = chan ^ 64;
     const int ntasks = (nq + 15) >> 4;
 
+    // sampling locations / weights of the lane's samples, requested one level ahead: their latency
+    // passes behind the previous level's scan, records and reduce phases
+    f2 xy_nx[kMaxTasks];
+    float a_nx[kMaxTasks];
+    auto request_level = [&](int l_) {
+#pragma unroll
+        for (int k = 0; k < kMaxTasks; ++k) {
+            const int t = wave + k * kWaves;
+            const int qi = t * 16 + slot;
+            xy_nx[k] = f2{0.f, 0.f};
+            a_nx[k] = 0.f;
+            if (t < ntasks && qi < nq) {
+                const size_t idx = (((size_t)n * Lq + qtab[qi]) * M + m) * 16 + l_ * 4 + j;
+                xy_nx[k] = reinterpret_cast<const f2 *>(loc)[idx];
+                a_nx[k] = attn[idx];
+            }
+        }
+    };
+    request_level(0);
+
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
         const int Hl = pm.H[l], Wl = pm.W[l], stl = pm.start[l];
@@ -250,9 +270,8 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
             s.yx = 0; s.lh = 0.f; s.lw = 0.f; s.a = 0.f; s.flags = 0; s.row = 0;
             const int qi = t * 16 + slot;
             if (t < ntasks && qi < nq) {
-                const size_t idx = (((size_t)n * Lq + qtab[qi]) * M + m) * 16 + l * 4 + j;
-                const f2 xy = reinterpret_cast<const f2 *>(loc)[idx];
-                s.a = attn[idx];
+                const f2 xy = xy_nx[k];
+                s.a = a_nx[k];
                 const float h_im = xy.y * Hf - 0.5f, w_im = xy.x * Wf - 0.5f;
                 const bool inside = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
                 if (inside) {
@@ -279,6 +298,7 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
             }
             smp[k] = s;
         }
+        if (l + 1 < 4) request_level(l + 1);
         TICK(1);                               // pass A: geometry + counts
         __syncthreads();
         TICK(2);                               // barriers + scan
