@@ -55,6 +55,9 @@
 #ifndef PYR2_OUT_NT
 #define PYR2_OUT_NT 1
 #endif
+#ifndef PYR2_DOTS_DEPTH
+#define PYR2_DOTS_DEPTH 1
+#endif
 #ifndef PYR2_BANDS
 #define PYR2_BANDS 1
 #endif
@@ -312,7 +315,7 @@ __device__ __forceinline__ void pyr2_body(
     constexpr int kP2Threads = kP2Configs[kCfg].threads, kP2Waves = kP2Threads / 64;
     // two samples' corner rows in flight where the register budget allows (168 VGPRs at 3 x 256 threads)
     // (the backward holds 12 results per task until its last level: one sample in flight at 128 VGPRs)
-    constexpr int kDepth = kDots ? (kCfg == 1 ? 2 : 1) : (kCfg == 1 || kTPW <= 2) ? 2 : 1;
+    constexpr int kDepth = kDots ? (kCfg == 1 ? 2 : PYR2_DOTS_DEPTH) : (kCfg == 1 || kTPW <= 2) ? 2 : 1;
     const int tid = threadIdx.x;
     const int nreg = pm.nRy * pm.nRx;
     const unsigned row_stride = (unsigned)M * kRowBytes;           // bytes between pixels of one head

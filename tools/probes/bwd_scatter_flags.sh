@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../.."
 C=datr_amd/csrc
-SETS="${PYRB_FLAGSETS:-base:-DPYRB_MASKED_READS=0 masked:-DPYRB_MASKED_READS=1}"
+SETS="${PYRB_FLAGSETS:-base:-DPYRB_REC_DPP=0 dpp:-DPYRB_REC_DPP=1}"
 if [ "$1" = build ]; then
   make -C $C >/dev/null
   OTHERS=$(ls $C/build/*.o | grep -v msda_bwd_pyr)
