@@ -245,6 +245,51 @@ def test_encoder_backward_does_not_depend_on_the_envelope(M, O, dev, env_kind):
     torch.testing.assert_close(gl.cpu()[keep], rl[keep], **tol(torch.float32, 100))
 
 
+_SINGLE_KERNEL_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from datr_amd import msda as M
+d = np.load(sys.argv[2])
+dev = torch.device("cuda:0")
+t = {k: torch.from_numpy(d[k]).to(dev) for k in d.files}
+env = M.measure_envelope(t["loc"], t["sh"])
+gv, gl, ga = M.ms_deform_attn_backward(t["value"], t["sh"], t["lsi"], t["loc"], t["attn"], t["go"], 64, envelope=env)
+np.savez(sys.argv[3], gv=gv.cpu().numpy(), gl=gl.cpu().numpy(), ga=ga.cpu().numpy())
+"""
+
+
+def test_encoder_backward_two_kernels_match_the_single_kernel(M, O, dev, tmp_path):
+    """The product backward of the encoder calls is two kernels (grad_loc / grad_attn out of the forward's
+    LDS windows, grad_value by a value-free sorted scatter); DATR_MSDA_BWD_SPLIT=0 keeps the single kernel
+    that gathers the corner rows itself (the path of shapes the forward's plan does not cover).  The switch
+    is read once per process, so the single kernel runs in a child process on the same inputs."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    N, Mh, D, P = 2, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, FULL_SHAPES, P, seed=51)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(52)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    loc = pyramid_locs(FULL_SHAPES, N, Mh, P, 2.0, seed=53)
+    go = torch.randn(N, S, Mh * D, generator=g)
+    d = [t.to(dev) for t in (value, sh, lsi, loc, attn, go)]
+    env = M.measure_envelope(d[3], d[1])
+    gv, gl, ga = M.ms_deform_attn_backward(d[0], d[1], d[2], d[3], d[4], d[5], 64, envelope=env)
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, value=value.numpy(), sh=sh.numpy(), lsi=lsi.numpy(), loc=loc.numpy(), attn=attn.numpy(), go=go.numpy())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", _SINGLE_KERNEL_SCRIPT, root, inp, out], check=True, timeout=600,
+                   env=dict(os.environ, DATR_MSDA_BWD_SPLIT="0"))
+    ref = np.load(out)
+    scale = float(np.abs(ref["gv"]).max())
+    torch.testing.assert_close(gv.cpu(), torch.from_numpy(ref["gv"]), rtol=1e-3, atol=1e-5 * scale)
+    torch.testing.assert_close(ga.cpu(), torch.from_numpy(ref["ga"]), **tol(torch.float32, 10))
+    keep = off_grid(loc, sh)
+    torch.testing.assert_close(gl.cpu()[keep], torch.from_numpy(ref["gl"])[keep], **tol(torch.float32, 100))
+
+
 # Cityscapes -> Foggy Cityscapes frames are 1024x2048 after the x1.5 scaling capped at 2048
 # (/root/reference/config/DA/Cityscapes2FoggyCityscapes/coco_transformer_C2F.py:1-7; SURVEY.md A.1):
 # the pyramid the mAP clause of the north star would run at.
