@@ -55,6 +55,9 @@
 #ifndef PYR2_OUT_NT
 #define PYR2_OUT_NT 1
 #endif
+#ifndef PYR2_ROW_LOC
+#define PYR2_ROW_LOC 1
+#endif
 #ifndef PYR2_DOTS_DEPTH
 #define PYR2_DOTS_DEPTH 1
 #endif
@@ -477,7 +480,30 @@ __device__ __forceinline__ void pyr2_body(
         for (int t = 0; t < kTPW; ++t)
             if (wave + t * kP2Waves < ntasks) dst[t] = load_sample(soff[t], l);
     };
-    load_level(nxt, 0);
+    // kRowLoc (the backward at two tasks per wave: 137 -> 131 us; the forward's 128 registers leave no room for
+    // the 12 values per task -- 95 -> 99 us --, three tasks per wave spill).  Whole rows instead: lane j loads LEVEL j's four points of its query -- 32 B of locations, 16 B of
+    // weights; a quad reads the (query, head)'s 128-B location row and 64-B weight row once, as whole lines
+    // -- and a 4 x 4 transpose inside the quad leaves it with POINT j of the four levels.  3 loads per task
+    // in place of 8 that each used 32 / 16 B of sixteen different lines.
+    constexpr bool kRowLoc = PYR2_ROW_LOC && kDots && kTPW <= 2;
+    float lx_[kRowLoc ? kTPW : 1][4], ly_[kRowLoc ? kTPW : 1][4], la_[kRowLoc ? kTPW : 1][4];
+    if constexpr (kRowLoc) {
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t)
+        if (wave + t * kP2Waves < ntasks) {
+            const f4 l0 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(loc_rsrc, (soff[t] + 4 * j) * 8, 0, 0));
+            const f4 l1 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(loc_rsrc, (soff[t] + 4 * j + 2) * 8, 0, 0));
+            const f4 a4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(attn_rsrc, (soff[t] + 4 * j) * 4, 0, 0));
+            lx_[t][0] = l0.x; ly_[t][0] = l0.y; lx_[t][1] = l0.z; ly_[t][1] = l0.w;
+            lx_[t][2] = l1.x; ly_[t][2] = l1.y; lx_[t][3] = l1.z; ly_[t][3] = l1.w;
+            la_[t][0] = a4.x; la_[t][1] = a4.y; la_[t][2] = a4.z; la_[t][3] = a4.w;
+            quad_transpose(lx_[t], j);
+            quad_transpose(ly_[t], j);
+            quad_transpose(la_[t], j);
+        }
+    } else {
+        load_level(nxt, 0);
+    }
     TICK(0);                                             // prologue: plan loads, query decode
 
     int next_phase = 0;
@@ -505,12 +531,20 @@ __device__ __forceinline__ void pyr2_body(
         const int lbase = lv[l].lbase;
         const int row_bytes = WW * kRowBytes;
 #pragma unroll
-        for (int t = 0; t < kTPW; ++t) cur[t] = nxt[t];
+        for (int t = 0; t < kTPW; ++t) {
+            if constexpr (kRowLoc) {
+                cur[t].xy = f2{lx_[t][l], ly_[t][l]};
+                cur[t].a = la_[t][l];
+            } else {
+                cur[t] = nxt[t];
+            }
+        }
 #ifdef PYR2_PROBE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         TICK(5);                                         // locations of this level landing
-        if (l + 1 < 4) load_level(nxt, l + 1);
+        if constexpr (!kRowLoc)
+            if (l + 1 < 4) load_level(nxt, l + 1);
 #pragma unroll
         for (int t = 0; t < kTPW; ++t) {
             const int ti = wave + t * kP2Waves;

@@ -19,7 +19,7 @@ else
     name=${fs%%:*}
     for d in ${P2_DISTS:-model}; do
     echo -n "$name dist=$d "
-    DATR_HIP_LIB=$PWD/datr_amd/lib/libdatr_hip_p2f_$name.so bash tools/probes/kernel_times.sh 3 python $PWD/tools/bench_msda.py --dist $d --n 4 --encoder-only --iters 20 --envelope measured | grep "bwd_dots" | cut -c60-
+    DATR_HIP_LIB=$PWD/datr_amd/lib/libdatr_hip_p2f_$name.so bash tools/probes/kernel_times.sh 3 python $PWD/tools/bench_msda.py --dist $d --n 4 --encoder-only --iters 20 --envelope measured | grep "msda_" | cut -c28-52,98-
     done
   done
 fi
