@@ -98,8 +98,10 @@ int datr_msda_backward_tiled_f32(const float *grad_out, const float *value, cons
                                  float *grad_loc, float *grad_attn, void *stream);
 /* datr_msda_backward_tiled_f32 with the measured offset envelope of the samples (as for
  * datr_msda_forward_pyramid_f32: [8][4]{oy_lo, oy_hi, ox_lo, ox_hi} pixels of the sampled level, host
- * memory, or NULL): the encoder calls' pyramid-region kernel sizes its windows by it.  Results do not
- * depend on it. */
+ * memory, or NULL): the encoder calls' pyramid-region kernels size their windows by it.  Results do not
+ * depend on it.  Two launches on `stream` for those calls: grad_loc / grad_attn out of the forward's LDS
+ * windows (msda_fwd_pyr2.hip, kDots), grad_value by the value-free sorted scatter (msda_bwd_pyr.hip);
+ * all three outputs are complete when the stream reaches the end of the second. */
 int datr_msda_backward_pyramid_f32(const float *grad_out, const float *value, const int64_t *shapes,
                                    const int64_t *level_start, const int64_t *shapes_host,
                                    const int64_t *level_start_host, const float *envelope_host,
