@@ -18,8 +18,8 @@
 //   * grad_loc / grad_attn of a sample are computed by the workgroup that owns the sample's
 //     (clamped) top-left pixel, gathering the four corner rows from global memory.
 // Scanning is cheap (geometry only: ~40 VALU operations per sample) compared with the
-// ~10x more expensive contributions it filters.  Fixed-point scale per workgroup =
-// 2^30 / (max|grad_out| * sum|attn| over the scanned samples).
+// ~10x more expensive contributions it filters.  Fixed-point scale per (image, head, level) =
+// 2^30 / (max|grad_out| * sum|attn| over its samples), worked out by a small kernel in front (owner_bounds).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -62,18 +62,67 @@ struct OwnerMeta {
     int range_base[DATR_TILED_MAX_LEVELS + 1];    // first range of each level; [L] = total
 };
 
+// Bound of the fixed-point scale, once per (image, head, level) instead of once per workgroup (54 ranges
+// of a head re-read all of its grad_out rows: 24 of the kernel's 149 us):
+//   max |grad_out[n, :, m, :]| * sum |attn[n, :, m, l, :]|
+// as kBoundParts partial results per (image, head) -- the queries in kBoundParts slices, one workgroup each:
+// parts[((n * M + m) * kBoundParts + c) * (1 + L) + {0: max, 1 + l: sum}] -- which every consumer combines
+// in the same fixed order (the scale, and with it grad_value, stays bitwise reproducible).
+constexpr int kBoundParts = 16;
+__global__ __launch_bounds__(256) void owner_bounds(const float *__restrict__ grad_out, const float *__restrict__ attn,
+                                                    int Lq, int M, int L, int P, float *__restrict__ bounds)
+{
+    constexpr int D = 32, kT = 256;
+    __shared__ float red[(1 + DATR_TILED_MAX_LEVELS) * (kT / 64)];
+    const int part = blockIdx.x % kBoundParts, nm = blockIdx.x / kBoundParts;
+    const int n = nm / M, m = nm % M, tid = threadIdx.x, K = L * P;
+    const int q_lo = (int)((long)Lq * part / kBoundParts), q_hi = (int)((long)Lq * (part + 1) / kBoundParts);
+    float mx = 0.f, asum[DATR_TILED_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < DATR_TILED_MAX_LEVELS; ++l) asum[l] = 0.f;
+    for (int i = q_lo * (D / 4) + tid; i < q_hi * (D / 4); i += kT) {
+        const int q = i >> 3, j = i & 7;
+        const float4 v = reinterpret_cast<const float4 *>(grad_out + (((size_t)n * Lq + q) * M + m) * D)[j];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int i = q_lo * K + tid; i < q_hi * K; i += kT) {
+        const int q = i / K, k = i - q * K, l = k / P;
+        const float a = fabsf(attn[(((size_t)n * Lq + q) * M + m) * K + k]);
+#pragma unroll
+        for (int ll = 0; ll < DATR_TILED_MAX_LEVELS; ++ll) asum[ll] += ll == l ? a : 0.f;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+#pragma unroll
+        for (int l = 0; l < DATR_TILED_MAX_LEVELS; ++l) asum[l] += __shfl_xor(asum[l], o, 64);
+    }
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = mx;
+#pragma unroll
+        for (int l = 0; l < DATR_TILED_MAX_LEVELS; ++l) red[(1 + l) * (kT / 64) + (tid >> 6)] = asum[l];
+    }
+    __syncthreads();
+    if (tid <= L) {                                   // 0: the maximum, 1 + l: level l's sum
+        float r = 0.f;
+        for (int w = 0; w < kT / 64; ++w) {
+            const float v = red[tid * (kT / 64) + w];
+            r = tid == 0 ? fmaxf(r, v) : r + v;
+        }
+        bounds[(size_t)blockIdx.x * (1 + L) + tid] = r;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, const OwnerMeta meta, int S,
     int M, int P, int Lq, float *__restrict__ grad_value, long gv_row_stride, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn)
+    float *__restrict__ grad_attn, const float *__restrict__ bounds)
 {
     constexpr int D = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Entry *queue = reinterpret_cast<Entry *>(smem);                                // 24 KB
     int *win = reinterpret_cast<int *>(smem + kThreads * sizeof(Entry));           // 52 KB
     int *ctl = reinterpret_cast<int *>(win + kRows * D);                           // [0] queue length
-    float *fctl = reinterpret_cast<float *>(ctl + 4);                              // 2 x kWaves
 
     const int R = meta.range_base[meta.L];
     const int bid = blockIdx.x;
@@ -87,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
     const int nrows = min(kRows, H * W - p0);
     const int K = meta.L * P;
 
-    const int tid = threadIdx.x, g = tid / kLPR, j = tid % kLPR, wave = tid >> 6;
+    const int tid = threadIdx.x, g = tid / kLPR, j = tid % kLPR;
     const unsigned row_bytes = (unsigned)(M * D) * 4u;
     const size_t item = ((size_t)n * S * M + m) * D;
     __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -95,27 +144,19 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
     const unsigned chan = (unsigned)j * 16u;
     const int nsamples = Lq * P;
 
-    // ---- pass 0: bound for the fixed-point scale: max |grad_out| (this head) * sum |attn| (level) --
-    float mx = 0.f, asum = 0.f;
-    for (int q = g; q < Lq; q += kGroups) {
-        const float4 v = reinterpret_cast<const float4 *>(grad_out + (((size_t)n * Lq + q) * M + m) * D)[j];
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    }
-    for (int s = tid; s < nsamples; s += kThreads) {
-        const int q = s / P, p = s - q * P;
-        asum += fabsf(attn[(((size_t)n * Lq + q) * M + m) * K + l * P + p]);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        asum += __shfl_xor(asum, o, 64);
-    }
-    if ((tid & 63) == 0) { fctl[wave] = mx; fctl[kWaves + wave] = asum; }
+    // ---- the bound of the fixed-point scale (owner_bounds); zero the accumulators ------------------
     for (int i = tid; i < kRows * (D / 4); i += kThreads)
         reinterpret_cast<int4 *>(win)[i] = make_int4(0, 0, 0, 0);
     if (tid == 0) ctl[0] = 0;
     __syncthreads();
     float maxgo = 0.f, asum_all = 0.f;
-    for (int w = 0; w < kWaves; ++w) { maxgo = fmaxf(maxgo, fctl[w]); asum_all += fctl[kWaves + w]; }
+    {
+        const float *pb = bounds + ((size_t)n * M + m) * kBoundParts * (1 + meta.L);
+        for (int c = 0; c < kBoundParts; ++c) {
+            maxgo = fmaxf(maxgo, pb[c * (1 + meta.L)]);
+            asum_all += pb[c * (1 + meta.L) + 1 + l];
+        }
+    }
     const float bound = maxgo * asum_all;
     const float scale = bound > 0.f ? 1073741824.f / bound : 0.f;      // 2^30 / bound
     const float inv_scale = bound * (1.f / 1073741824.f);
@@ -252,9 +293,19 @@ extern "C" int datr_internal_msda_bwd_owner_d32(
     meta.range_base[tm->L] = base;
     const int64_t blocks = N * M * base;
     if (blocks <= 0 || blocks > 0x7fffffff || Lq * P > 0x3fffffff) return DATR_EUNSUPPORTED;
+    if (tm->L > DATR_TILED_MAX_LEVELS || Lq * tm->L * P > 0x3fffffff) return DATR_EUNSUPPORTED;
     const size_t lds = kThreads * sizeof(Entry) + (size_t)kRows * 32 * 4 + 16 + 2 * kWaves * 4;
-    hipLaunchKernelGGL(msda_bwd_owner_d32, dim3((unsigned)blocks), dim3(kThreads), lds,
-                       (hipStream_t)stream, grad_out, value, loc, attn, meta, (int)S, (int)M, (int)P,
-                       (int)Lq, grad_value, (long)grad_value_row_stride, grad_loc, grad_attn);
-    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+    // N * M * kBoundParts * (1 + L) floats of stream-ordered scratch for the bounds: allocated and released on `stream`
+    hipStream_t st = (hipStream_t)stream;
+    float *bounds = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&bounds), (size_t)(N * M * kBoundParts * (1 + tm->L)) * sizeof(float), st) != hipSuccess)
+        return DATR_ELAUNCH;
+    hipLaunchKernelGGL(owner_bounds, dim3((unsigned)(N * M * kBoundParts)), dim3(256), 0, st, grad_out, attn, (int)Lq, (int)M,
+                       tm->L, (int)P, bounds);
+    hipLaunchKernelGGL(msda_bwd_owner_d32, dim3((unsigned)blocks), dim3(kThreads), lds, st, grad_out, value, loc, attn,
+                       meta, (int)S, (int)M, (int)P, (int)Lq, grad_value, (long)grad_value_row_stride, grad_loc,
+                       grad_attn, bounds);
+    const bool launched = hipGetLastError() == hipSuccess;
+    const bool freed = hipFreeAsync(bounds, st) == hipSuccess;
+    return launched && freed ? DATR_OK : DATR_ELAUNCH;
 }
