@@ -29,11 +29,17 @@
 
 namespace {
 
-constexpr int kThreads = 768;           // 2 workgroups per CU = 6 waves per SIMD (76 KB of LDS each)
+#ifndef OWNER_THREADS
+#define OWNER_THREADS 768
+#endif
+#ifndef OWNER_ROWS
+#define OWNER_ROWS 416
+#endif
+constexpr int kThreads = OWNER_THREADS; // 2 workgroups per CU = 6 waves per SIMD (76 KB of LDS each)
 constexpr int kWaves = kThreads / 64;
 constexpr int kLPR = 8;                 // lanes per 32-channel row (float4 each)
 constexpr int kGroups = kThreads / kLPR;
-constexpr int kRows = 416;              // value rows owned by a workgroup (52 KB of accumulators)
+constexpr int kRows = OWNER_ROWS;            // value rows owned by a workgroup (52 KB of accumulators)
 constexpr unsigned kOutOfRange = 0x80000000u;
 
 struct Entry {               // 32 B: a sample that concerns this workgroup
