@@ -37,8 +37,6 @@ _SIGNATURES = {
     "datr_affine_act_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
     "datr_affine_act_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
     "datr_affine_act_backward2_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
-    "datr_conv3x3_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
-                                 ctypes.c_float, _vp, _vp],
     "datr_add_layernorm_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp],
     "datr_add_layernorm_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "datr_normalize_pad_u8_f32": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
@@ -57,9 +55,7 @@ _SIGNATURES = {
     "datr_sine_embed_f32": [_vp, _vp, _i64, _i64, _vp, _vp],
     "datr_topk_rows_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "datr_nms_f32": [_vp, _vp, _vp, _i64, ctypes.c_float, _vp, _vp, _vp],
-    "datr_gemm_k256_f32": [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp],
-    "datr_conv3x3_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
-                                      ctypes.c_float, _vp, _vp],
+    "datr_gemm_f32": [ctypes.c_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "datr_relu_bwd_bias_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_resize_bilinear_u8": [_vp, _i64, _i64, ctypes.c_int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp,
                                 _vp, _vp],
@@ -89,6 +85,12 @@ _SIGNATURES = {
     "datr_focal_loss_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float,
                                      ctypes.c_float, _vp, _vp],
 }
+
+
+class GemmEpilogue(ctypes.Structure):
+    """`datr_gemm_epilogue` of include/datr_hip.h."""
+    _fields_ = [("scale", _vp), ("shift", _vp), ("residual", _vp), ("ldr", _i64), ("gate", _vp), ("ldg", _i64),
+                ("relu", ctypes.c_int), ("colsum", _vp)]
 
 
 class WinoLevel(ctypes.Structure):
@@ -138,6 +140,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_conv3x3_cout1_partial_floats.argtypes = [_vp, _i64, _i64]
     lib.datr_ema_piece_elements.restype = ctypes.c_int64
     lib.datr_ema_piece_elements.argtypes = []
+    lib.datr_gemm_workspace_floats.restype = ctypes.c_int64
+    lib.datr_gemm_workspace_floats.argtypes = [ctypes.c_int, _i64, _i64, _i64, ctypes.c_int]
     lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64
     lib.datr_wgrad_k256_scratch_floats.argtypes = []
     for name, argtypes in _SIGNATURES.items():

@@ -24,7 +24,7 @@ from torch import nn
 from .fused import fan_out, frozen_bn_act
 from . import strided
 from .wino import conv3x3_bn_relu, conv3x3_own_wgrad
-from . import pointwise
+from . import bottleneck, pointwise
 from .nested import NestedTensor
 
 
@@ -140,12 +140,83 @@ class Bottleneck(nn.Module):
         return frozen_bn_act(y3, *self.bn3.scale_shift(), residual=identity, relu=True)
 
     def fold_pairs(self):
-        """(weight, frozen scale) of the 1x1 convolutions whose batch norm is folded into the GEMM:
-        conv1 and the downsample convolution."""
-        pairs = [(self.conv1.weight, self.bn1.scale_shift()[0])]
+        """(slot, weight, frozen scale) of the 1x1 convolutions whose batch norm is folded into the GEMM:
+        slot 0 conv1, 1 the downsample convolution, 2 conv3 (the own bottleneck node)."""
+        pairs = [(0, self.conv1.weight, self.bn1.scale_shift()[0])]
         if self.downsample is not None and self.downsample[0].stride in ((1, 1), (2, 2)):
-            pairs.append((self.downsample[0].weight, self.downsample[1].scale_shift()[0]))
+            pairs.append((1, self.downsample[0].weight, self.downsample[1].scale_shift()[0]))
+        pairs.append((2, self.conv3.weight, self.bn3.scale_shift()[0]))
         return pairs
+
+    def own_node(self, x, gate_in: bool, gated_out: bool):
+        """The whole block as one autograd node on the own kernels (datr_amd.bottleneck), or None when
+        that node does not cover this block / input."""
+        folded = getattr(self, "_folded", None)
+        if folded is None or not isinstance(self.bn1, FrozenBatchNorm2d) or isinstance(x, tuple):
+            return None
+        stride = self.conv2.stride[0]
+        if self.conv2.stride not in ((1, 1), (2, 2)) or not bottleneck.applicable(x, self.conv2.out_channels, stride):
+            return None
+        wds = shiftd = None
+        if self.downsample is not None:
+            if folded[1] is None or self.downsample[0].stride != self.conv2.stride:
+                return None
+            wds, shiftd = folded[1], self.downsample[1].scale_shift()[1]
+        scale2, shift2 = self.bn2.scale_shift()
+        return bottleneck.bottleneck(x, folded[0], self.conv2.weight, folded[2], wds, self.bn1.scale_shift()[1],
+                                     scale2, shift2, self.bn3.scale_shift()[1], shiftd, stride, gate_in, gated_out)
+
+
+class BottleneckStage(nn.Sequential):
+    """A ResNet stage.  Blocks the own node covers are chained with the ReLU backward of a block's
+    output applied by the NEXT block's data-gradient epilogue (datr_amd.bottleneck): a block's
+    gradient then arrives gated (`gated_out`) and its consumer gates (`gate_in`)."""
+
+    def forward(self, x):
+        blocks = list(self)
+        pair = isinstance(x, tuple)          # two handles on one tensor (fused.fan_out): conv1 / identity
+        probe = x[0] if pair else x
+        own = [False] * len(blocks)
+        # which blocks take the own node is decided from the stage input (all blocks of a stage see
+        # the same layout / dtype; the pixel count only shrinks at block 0)
+        usable = (bottleneck.OWN_BOTTLENECK and isinstance(probe, torch.Tensor) and probe.is_cuda
+                  and probe.dtype == torch.float32 and probe.dim() == 4 and not torch.is_autocast_enabled()
+                  and probe.is_contiguous(memory_format=torch.channels_last) and not probe.is_contiguous())
+        out_pixels = 0
+        for i, blk in enumerate(blocks):
+            if not (usable and isinstance(blk, Bottleneck) and getattr(blk, "_folded", None) is not None
+                    and isinstance(blk.bn1, FrozenBatchNorm2d)):
+                break
+            stride = blk.conv2.stride[0]
+            if i == 0:
+                ok = blk.conv2.stride in ((1, 1), (2, 2)) and bottleneck.applicable(probe, blk.conv2.out_channels, stride) \
+                    and (blk.downsample is None or (blk._folded[1] is not None and blk.downsample[0].stride == blk.conv2.stride))
+                N, _, H, W = probe.shape
+                out_pixels = N * ((H + stride - 1) // stride) * ((W + stride - 1) // stride)
+            else:
+                ok = (blk.downsample is None and blk.conv2.stride == (1, 1) and out_pixels >= bottleneck.MIN_PIXELS
+                      and blk.conv2.out_channels % 64 == 0)
+            own[i] = ok
+            if not ok:
+                break
+        x_id = x
+        if pair:
+            x, x_id = x
+            if own[0]:                       # the node takes ONE handle; the other one stays without a gradient
+                x_id = x
+        for i, blk in enumerate(blocks):
+            y = None
+            if own[i]:
+                gate_in = i > 0 and own[i - 1] and torch.is_grad_enabled()
+                gated_out = i + 1 < len(blocks) and own[i + 1] and torch.is_grad_enabled()
+                y = blk.own_node(x, gate_in, gated_out)
+                assert y is not None or not (gate_in or gated_out), "own bottleneck chain broken"
+            if y is None:
+                y = blk((x, x_id) if x is not x_id else x)
+            x = x_id = y
+            if isinstance(y, tuple):
+                x, x_id = y
+        return (x, x_id) if x is not x_id else x
 
 
 class ResNet50Body(nn.Module):
@@ -167,7 +238,7 @@ class ResNet50Body(nn.Module):
                        for _ in range(blocks - 1)]
             for blk in layers[:-1]:                  # their successor has no downsample branch: see pair_out
                 blk.pair_out = True
-            setattr(self, f"layer{idx}", nn.Sequential(*layers))
+            setattr(self, f"layer{idx}", BottleneckStage(*layers))
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -213,12 +284,12 @@ class _StageOutputs(nn.ModuleDict):
             return
         pairs, owner = [], []
         for b in blocks:
-            for k, pr in enumerate(b.fold_pairs()):
-                pairs.append(pr)
-                owner.append((b, k))
+            for slot, w, sc in b.fold_pairs():
+                pairs.append((w, sc))
+                owner.append((b, slot))
         folded = pointwise.fold_frozen_bn(pairs)
         for b in blocks:
-            b._folded = [None, None]
+            b._folded = [None, None, None]
         for (b, k), f in zip(owner, folded):
             b._folded[k] = f
 

@@ -42,6 +42,7 @@ class _AffineAct(Function):
         ctx.relu, ctx.has_res = bool(relu), res is not None
         ctx.save_for_backward(y if relu else None, scale)
         ctx.shape = (C, inner, fmt)
+        ctx.set_materialize_grads(False)         # an unused handle of `twice` arrives as None
         # twice: two handles on y for its two consumers (the next bottleneck's conv1 and identity
         # branch); their gradients are summed inside the backward kernel
         return (y, y.view_as(y)) if twice else y
@@ -54,6 +55,8 @@ class _AffineAct(Function):
         C, inner, fmt = ctx.shape
         if dy is None:
             dy, dy2 = dy2, None
+        if dy is None:
+            return None, None, None, None, None, None
         dy = dy.contiguous(memory_format=fmt)
         if dy2 is not None:
             dy2 = dy2.contiguous(memory_format=fmt)
@@ -153,26 +156,31 @@ class GroupNormNHWC(torch.nn.GroupNorm):
         return super().forward(x)
 
 
-def conv3x3_lrelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None,
-                  slope: float = 1.0, out_scale: float = 1.0) -> torch.Tensor:
-    """out_scale * leaky_relu(conv2d(x, weight, bias, stride 1, padding 1), slope) as ONE
-    exact-fp32 MFMA implicit-GEMM kernel (csrc/conv3x3.hip) -- the layer shape of
-    `FCDiscriminator_img` (/root/reference/models/dino/DA_utils.py:61-79).  Forward only
-    (no autograd); measured against MIOpen in tools/bench_conv3x3.py."""
-    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-    N, Cin, H, W = x.shape
-    Cout = weight.shape[0]
-    assert weight.shape == (Cout, Cin, 3, 3)
-    wt = weight.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).contiguous()
-    x = x.contiguous()
-    y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
-        rc = _native.lib.datr_conv3x3_forward_f32(
-            x.data_ptr(), wt.data_ptr(), 0 if bias is None else bias.contiguous().data_ptr(),
-            N, Cin, Cout, H, W, float(slope), float(out_scale), y.data_ptr(),
-            _native.current_stream_ptr(x.device))
-    _native.check(rc, "conv3x3_forward")
-    return y
+FFN_FUSED_DZ = os.environ.get("DATR_FFN_FUSED_DZ", "1") != "0"
+FFN_FUSED_DZ_MIN_ROWS = int(os.environ.get("DATR_FFN_FUSED_DZ_MIN_ROWS", "16384"))
+
+
+def _ffn_hidden_gradient(dy2: torch.Tensor, w2: torch.Tensor, h: torch.Tensor):
+    """(dz, db1) with dz = (dy2 @ w2) * [h > 0] and db1 = column sums of dz -- the gradient at the FFN's
+    hidden pre-activation and linear1's bias gradient (deformable_transformer.py:803-806 under autograd).
+    Many rows: ONE launch of the own MFMA GEMM whose epilogue applies the ReLU mask and emits the column
+    sums (csrc/gemm_f32.hip) -- no pass over the rows x d_ffn tensor.  Few rows (the decoder): the library
+    GEMM followed by the in-place mask + bias-gradient pass (csrc/ffn.hip)."""
+    rows = dy2.shape[0]
+    cols = w2.shape[1]
+    if (FFN_FUSED_DZ and rows >= FFN_FUSED_DZ_MIN_ROWS and w2.is_contiguous() and h.is_contiguous()
+            and dy2.shape[1] % 32 == 0 and cols % 4 == 0 and rows * cols < (1 << 29)):
+        from . import gemm
+        return gemm.gemm_nn(dy2, w2, gate=h, colsum=True)
+    dh = dy2.mm(w2)                                       # rows x d_ffn, ours to overwrite
+    db1 = torch.empty(cols, device=dh.device, dtype=dh.dtype)
+    nblk = int(_native.lib.datr_relu_bwd_bias_partial_rows(rows))
+    partial = torch.empty(nblk * cols, device=dh.device, dtype=dh.dtype)
+    with torch.cuda.device(dh.device):
+        rc = _native.lib.datr_relu_bwd_bias_f32(dh.data_ptr(), h.data_ptr(), rows, cols, partial.data_ptr(),
+                                                db1.data_ptr(), _native.current_stream_ptr(dh.device))
+    _native.check(rc, "relu_bwd_bias")
+    return dh, db1
 
 
 class _FFNRelu(Function):
@@ -181,8 +189,9 @@ class _FFNRelu(Function):
     forward   h = relu(x W1^T + b1) as ONE hipBLASLt GEMM with a bias+ReLU epilogue
               (`torch._addmm_activation`; bit-identical to linear followed by relu, and no
               separate clamp pass over the rows x d_ffn activation);  y = h W2^T + b2.
-    backward  dh = dy W2;  dz = dh * (h > 0) in place together with db1 = sum_rows(dz) in one HBM
-              pass (csrc/ffn.hip);  dx = dz W1,  dW1 = dz^T x,  dW2 = dy^T h,  db2 = sum_rows(dy).
+    backward  dz = (dy W2) * (h > 0) and db1 = sum_rows(dz) as ONE own MFMA GEMM whose epilogue applies
+              the mask and emits the column sums (`_ffn_hidden_gradient`; few rows: library GEMM + one
+              in-place pass, csrc/ffn.hip);  dx = dz W1,  dW1 = dz^T x,  dW2 = dy^T h,  db2 = sum_rows(dy).
     Same saved activations as autograd's own graph (x and h)."""
 
     @staticmethod
@@ -207,16 +216,7 @@ class _FFNRelu(Function):
         need = ctx.needs_input_grad
         dw2 = dy2.t().mm(h) if need[3] else None
         db2 = column_sums(dy2) if need[4] else None
-        dh = dy2.mm(w2)                                   # rows x d_ffn, ours to overwrite
-        rows, cols = dh.shape
-        db1 = torch.empty(cols, device=dh.device, dtype=dh.dtype)
-        nblk = int(_native.lib.datr_relu_bwd_bias_partial_rows(rows))
-        partial = torch.empty(nblk * cols, device=dh.device, dtype=dh.dtype)
-        with torch.cuda.device(dh.device):
-            rc = _native.lib.datr_relu_bwd_bias_f32(
-                dh.data_ptr(), h.data_ptr(), rows, cols, partial.data_ptr(), db1.data_ptr(),
-                _native.current_stream_ptr(dh.device))
-        _native.check(rc, "relu_bwd_bias")
+        dh, db1 = _ffn_hidden_gradient(dy2, w2, h)
         dw1 = dh.t().mm(x2) if need[1] else None
         dx = dh.mm(w1).view(ctx.shape) if need[0] else None
         return dx, dw1, (db1 if need[2] else None), dw2, db2
@@ -339,15 +339,7 @@ class _FFNAddNorm(Function):
         need = ctx.needs_input_grad
         dw2 = dsum.t().mm(h) if need[3] else None
         db2 = column_sums(dsum) if need[4] else None
-        dh = dsum.mm(w2)                                  # rows x d_ffn, ours to overwrite
-        cols = dh.shape[1]
-        db1 = torch.empty(cols, device=dh.device, dtype=dh.dtype)
-        nblk = int(_native.lib.datr_relu_bwd_bias_partial_rows(rows))
-        part2 = torch.empty(nblk * cols, device=dh.device, dtype=dh.dtype)
-        with torch.cuda.device(dh.device):
-            rc = _native.lib.datr_relu_bwd_bias_f32(dh.data_ptr(), h.data_ptr(), rows, cols, part2.data_ptr(),
-                                                    db1.data_ptr(), stream)
-        _native.check(rc, "relu_bwd_bias")
+        dh, db1 = _ffn_hidden_gradient(dsum, w2, h)
         dw1 = dh.t().mm(x2) if need[1] else None
         dx = torch.addmm(dsum, dh, w1).view(ctx.shape) if need[0] else None
         return (dx, dw1, db1 if need[2] else None, dw2, db2, dgamma if need[5] else None,
@@ -426,6 +418,7 @@ class _FanOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.n = n
+        ctx.set_materialize_grads(False)         # an unused handle arrives as None, not as a zero tensor
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
@@ -557,28 +550,6 @@ class FastLinear(torch.nn.Linear):
 
     def forward(self, x):
         return linear(x, self.weight, self.bias)
-
-
-def conv3x3_lrelu_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None,
-                       slope: float = 1.0, out_scale: float = 1.0) -> torch.Tensor:
-    """conv3x3_lrelu for torch.channels_last tensors (csrc/conv3x3_nhwc.hip: the input patch of a
-    channel chunk is staged in LDS once for all nine taps).  Forward only; Cin % 16 == 0,
-    Cout % 128 == 0.  Returns a channels_last tensor."""
-    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-    N, Cin, H, W = x.shape
-    Cout = weight.shape[0]
-    assert weight.shape == (Cout, Cin, 3, 3)
-    x = x.contiguous(memory_format=torch.channels_last)
-    wt = weight.permute(2, 3, 1, 0).contiguous()
-    y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32,
-                    memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
-        rc = _native.lib.datr_conv3x3_nhwc_forward_f32(
-            x.data_ptr(), wt.data_ptr(), 0 if bias is None else bias.contiguous().data_ptr(),
-            N, H, W, Cin, Cout, float(slope), float(out_scale), y.data_ptr(),
-            _native.current_stream_ptr(x.device))
-    _native.check(rc, "conv3x3_nhwc_forward")
-    return y
 
 
 # ---------------------------------------------------------------------------------------------

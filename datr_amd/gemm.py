@@ -1,0 +1,96 @@
+"""Python front-end of the exact-fp32 MFMA GEMM family with fused epilogues (csrc/gemm_f32.hip).
+
+    gemm_nt(x, w, ...)   y  = epi(x @ w.T)     x [M, K], w [N, K]   -- a linear layer / 1x1 convolution
+    gemm_nn(dy, w, ...)  dx = epi(dy @ w)      dy [M, K], w [K, N]  -- its data gradient
+    gemm_tn(dy, x, ...)  dw = dy.T @ x         dy [P, M], x [P, N]  -- its weight gradient (split-K)
+
+Operands are 2-d float32 device tensors whose LAST stride is 1 (row slices of wider matrices are
+fine: the leading dimension is the row stride).  There is no fallback: an unsupported shape raises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native
+
+NT, NN, TN = 0, 1, 2
+_workspaces = {}
+
+
+def _workspace(device, stream: int, floats: int):
+    """Scratch per (device, stream), grown on demand; the kernels of one stream run in order, so a
+    later call may overwrite what an earlier one has finished with."""
+    if floats <= 0:
+        return None
+    key = (device, stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(int(floats * 1.25) + 1024, device=device, dtype=torch.float32)
+        _workspaces[key] = ws
+    return ws
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 and t.is_cuda, (t.shape, t.stride(), t.dtype)
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _run(form, A, B, M, N, K, out, scale, shift, residual, gate, relu, colsum):
+    dev = A.device
+    if out is None:
+        out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    epi = _native.GemmEpilogue()
+    epi.scale = 0 if scale is None else scale.data_ptr()
+    epi.shift = 0 if shift is None else shift.data_ptr()
+    epi.residual = 0 if residual is None else residual.data_ptr()
+    epi.ldr = 0 if residual is None else _ld(residual)
+    epi.gate = 0 if gate is None else gate.data_ptr()
+    epi.ldg = 0 if gate is None else _ld(gate)
+    epi.relu = int(bool(relu))
+    cs = None
+    if colsum:
+        cs = torch.empty(N, device=dev, dtype=torch.float32)
+    epi.colsum = 0 if cs is None else cs.data_ptr()
+    for t in (scale, shift):
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+    if residual is not None:
+        assert residual.shape == (M, N)
+    if gate is not None:
+        assert gate.shape == (M, N)
+    stream = _native.current_stream_ptr(dev)
+    need = int(_native.lib.datr_gemm_workspace_floats(form, M, N, K, int(bool(colsum))))
+    if form == TN and scale is not None:
+        need = max(need, M * N)
+    ws = _workspace(dev, stream, need)
+    with torch.cuda.device(dev):
+        rc = _native.lib.datr_gemm_f32(form, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), M, N, K,
+                                       ctypes.addressof(epi), out.data_ptr(), _ld(out),
+                                       0 if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), stream)
+    _native.check(rc, "gemm_f32")
+    return (out, cs) if colsum else out
+
+
+def gemm_nt(x, w, *, out=None, scale=None, shift=None, residual=None, gate=None, relu=False, colsum=False):
+    """epi(x @ w.T): x [M, K], w [N, K]; epi = gate(relu(v * scale[n] + shift[n] + residual))."""
+    M, K = x.shape
+    N, K2 = w.shape
+    assert K == K2
+    return _run(NT, x, w, M, N, K, out, scale, shift, residual, gate, relu, colsum)
+
+
+def gemm_nn(dy, w, *, out=None, scale=None, shift=None, residual=None, gate=None, relu=False, colsum=False):
+    """epi(dy @ w): dy [M, K], w [K, N]."""
+    M, K = dy.shape
+    K2, N = w.shape
+    assert K == K2
+    return _run(NN, dy, w, M, N, K, out, scale, shift, residual, gate, relu, colsum)
+
+
+def gemm_tn(dy, x, *, out=None, rowscale=None):
+    """dy.T @ x (optionally * rowscale[:, None]): dy [P, M], x [P, N] -> [M, N]; deterministic split over P."""
+    P, M = dy.shape
+    P2, N = x.shape
+    assert P == P2
+    return _run(TN, dy, x, M, N, P, out, rowscale, None, None, None, False, False)

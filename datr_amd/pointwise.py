@@ -7,8 +7,8 @@ faster forward and for the data gradient (tools/probes/conv1x1_gemm_probe.py), a
 epilogue takes the frozen batch norm that follows conv1 of every ResNet bottleneck
 (/root/reference/models/dino/backbone.py:62-72 around torchvision's Bottleneck):
     relu(bn(conv1(x))) = relu(x2d @ (W * scale)^T + shift)          -- ONE GEMM, no affine pass.
-The weight gradient stays a MIOpen convolution where that is faster (large pixel counts: its
-split-K kernels beat a GEMM whose reduction axis is 267 200 long) and is a GEMM on the small maps.
+The weight gradient is the own split-K kernel (datr_amd.gemm.gemm_tn) on the large maps (a library
+GEMM whose reduction axis is 10^4 .. 10^5 long loses by up to 2.5x) and a library GEMM on the small ones.
 
 `fold_frozen_bn` multiplies the weights of many layers by their frozen scales in ONE multi-tensor
 launch each way (folded weights of frozen layers are cached).
@@ -25,8 +25,8 @@ from . import _native
 
 # 0 = the library convolutions (A/B measurements)
 GEMM_1X1 = os.environ.get("DATR_CONV1X1_GEMM", "1") != "0"
-# weight gradient as a GEMM below this many pixels (measured: 4 x 25 x 42 = 4 200 pixels win by
-# 7-13 %, 16 800 and more lose by 10-150 %)
+# weight gradient as a LIBRARY GEMM below this many pixels (measured: at 4 x 25 x 42 = 4 200 pixels it
+# is 65-75 us against 79-90 us for the own split-K kernel; at 16 800 and more the own kernel wins 1.6-4x)
 WGRAD_GEMM_MAX_PIXELS = int(os.environ.get("DATR_CONV1X1_WGRAD_GEMM_MAX_PIXELS", "5000"))
 
 _ONES = {}
@@ -80,13 +80,14 @@ class _Conv1x1(Function):
         if need[0]:
             dx = dz2.mm(w2).view(N, H, W, C).permute(0, 3, 1, 2)
         if need[1]:
+            x2 = x.permute(0, 2, 3, 1).reshape(-1, C)
             if N * H * W <= WGRAD_GEMM_MAX_PIXELS:
-                dw = dz2.t().mm(x.permute(0, 2, 3, 1).reshape(-1, C))
+                dw = dz2.t().mm(x2)
             else:
-                _, dw4, _ = torch.ops.aten.convolution_backward(
-                    dz, x, w2.view(co, C, 1, 1), None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                    [False, True, False])
-                dw = dw4.reshape(co, C)
+                # deterministic split-K product over the pixels on the own MFMA kernel (csrc/gemm_f32.hip):
+                # a library GEMM whose reduction axis is 10^4 .. 10^5 long loses by up to 2.5x
+                from . import gemm
+                dw = gemm.gemm_tn(dz2, x2)
         if ctx.has_bias and need[2]:
             from .fused import column_sums
             db = column_sums(dz2)
@@ -114,6 +115,7 @@ class _FoldMany(Function):
     def forward(ctx, n, *args):
         ws, ss = args[:n], args[n:]
         ctx.save_for_backward(*ss)
+        ctx.set_materialize_grads(False)         # a folded weight nobody used gets no gradient
         return tuple(torch._foreach_mul(list(ws), [s.view(-1, 1) for s in ss]))
 
     @staticmethod

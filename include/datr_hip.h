@@ -219,28 +219,6 @@ int datr_affine_act_backward2_f32(const float *dy, const float *dy2, const float
                                   void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * 3x3 / stride 1 / pad 1 convolution, NCHW fp32, exact-fp32 MFMA implicit GEMM, with fused
- * bias + LeakyReLU epilogue -- the layers of the image-level domain discriminator
- * (`FCDiscriminator_img`, /root/reference/models/dino/DA_utils.py:61-79).
- *   x  [N, Cin, H, W]     wt [9*Cin, Cout]  = W.permute(2,3,1,0).reshape(9*Cin, Cout)
- *   y  [N, Cout, H, W]  = out_scale * lrelu_slope( bias + conv3x3(x, W) )
- * `bias` may be NULL; slope 1 = no activation.  Cin must be a multiple of 16.
- * The data gradient is the same call on dY with the transformed weights
- * W'[ci,co,r,s] = W[co,ci,2-r,2-s]; out_scale = -1 folds a gradient-reversal layer in.
- * ------------------------------------------------------------------------------------------ */
-int datr_conv3x3_forward_f32(const float *x, const float *wt, const float *bias,
-                             int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
-                             float slope, float out_scale, float *y, void *stream);
-
-/* Same convolution on NHWC (torch.channels_last) tensors, the layout the backbone runs in:
- *   x [N, H, W, Cin]   wt [3, 3, Cin, Cout] = W.permute(2, 3, 1, 0)   y [N, H, W, Cout]
- * Cin % 16 == 0, Cout % 128 == 0.  The input patch of a channel chunk is staged in LDS once and
- * re-used by all nine taps (csrc/conv3x3_nhwc.hip). */
-int datr_conv3x3_nhwc_forward_f32(const float *x, const float *wt, const float *bias, int64_t N,
-                                  int64_t H, int64_t W, int64_t Cin, int64_t Cout, float slope,
-                                  float out_scale, float *y, void *stream);
-
-/* ------------------------------------------------------------------------------------------
  * Winograd F(2x2, 3x3) convolution on the MFMA units (csrc/wino.hip), exact fp32, NHWC, 3x3 /
  * stride 1 / pad 1 -- the image-level domain discriminator's layers
  * (/root/reference/models/dino/DA_utils.py:61-79, call site dino.py:351-359), all pyramid levels in
@@ -551,16 +529,46 @@ int datr_sine_embed_f32(const float *pos, const float *dim_t, int64_t rows, int6
                         float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * Tall-skinny fp32 MFMA GEMM with K = 256: y[M, N] = x[M, 256] * B[256, N] (+ bias[N]); the
- * value / output / sampling-offset projections of MSDeformAttn
- * (/root/reference/models/dino/ops/modules/ms_deform_attn.py:92-95,118-124: nn.Linear(256, .) on
- * all encoder tokens) and their data gradients.  B[k][n] = b[k * ldk + n * ldn]:
- * (ldk, ldn) = (1, 256) computes x W^T for a row-major weight W[N][256] (F.linear forward),
- * (N, 1) computes dy W for W[256][N] (its data gradient when out_features == 256).
- * N % 128 == 0, N <= 2048; x, y contiguous row-major; bias may be NULL.  Exact fp32
- * (v_mfma_f32_32x32x2_f32), K summed in ascending pairs (j, j + 16) per 32-chunk. */
-int datr_gemm_k256_f32(const float *x, const float *b, int64_t ldk, int64_t ldn,
-                       const float *bias, int64_t M, int64_t N, float *y, void *stream);
+ * Exact-fp32 MFMA GEMM family with programmable epilogues (csrc/gemm_f32.hip): the 1x1
+ * convolutions of the NHWC ResNet-50 bottlenecks and of input_proj
+ * (/root/reference/models/dino/backbone.py:62-72,109-128 around torchvision's Bottleneck;
+ * /root/reference/models/dino/dino.py:111-119) -- forward with frozen BN (+ residual) (+ ReLU) in the
+ * epilogue, data gradient with the ReLU gate / identity-branch gradient in the epilogue, weight
+ * gradient as a deterministic split-K product -- and the FFN backward's dz = (dy W2) * [h > 0]
+ * with linear1's bias gradient (/root/reference/models/dino/deformable_transformer.py:783-787,803-806).
+ *
+ *   C[M, N] = epi( op(A) op(B) )        all matrices row-major fp32, leading dimensions in floats
+ *   form DATR_GEMM_NT:  A [M, K] (lda),  B [N, K] (ldb)     y  = x W^T
+ *   form DATR_GEMM_NN:  A [M, K] (lda),  B [K, N] (ldb)     dx = dy W
+ *   form DATR_GEMM_TN:  A [K, M] (lda),  B [K, N] (ldb)     dW = dy^T x   (reduction split over
+ *                       workgroups, partial products added in a fixed order: deterministic)
+ *   NT / NN:  epi(v)[m, n] = gate( relu( v * scale[n] + shift[n] + residual[m, n] ) ),
+ *             gate(v) = gate[m, n] > 0 ? v : 0;  colsum[n] = sum_m epi(v)[m, n]  (deterministic)
+ *   TN:       epi(v)[m, n] = v * scale[m]   (per-ROW scale: the frozen-BN fold of a weight gradient);
+ *             the other fields must be NULL / 0.
+ * Every epilogue field may be NULL / 0; `epi` itself may be NULL.
+ * Constraints: pointers 16-byte aligned, leading dimensions and N multiples of 4 (TN: M too);
+ * NT / NN: K % 32 == 0.  Every matrix < 2^31 bytes.  Otherwise DATR_EUNSUPPORTED.
+ * `workspace`: datr_gemm_workspace_floats(form, M, N, K, colsum != NULL) floats (0 = none needed),
+ * caller-owned, reusable by later calls on the same stream.
+ * ------------------------------------------------------------------------------------------ */
+#define DATR_GEMM_NT 0
+#define DATR_GEMM_NN 1
+#define DATR_GEMM_TN 2
+typedef struct {
+    const float *scale;      /* [N] (NT / NN) or [M] (TN), or NULL                                */
+    const float *shift;      /* [N] or NULL                                                       */
+    const float *residual;   /* [M, N] with leading dimension ldr, or NULL                        */
+    int64_t ldr;
+    const float *gate;       /* [M, N] with leading dimension ldg, or NULL                        */
+    int64_t ldg;
+    int relu;
+    float *colsum;           /* [N] column sums of the result, or NULL                            */
+} datr_gemm_epilogue;
+int64_t datr_gemm_workspace_floats(int form, int64_t M, int64_t N, int64_t K, int want_colsum);
+int datr_gemm_f32(int form, const float *A, int64_t lda, const float *B, int64_t ldb,
+                  int64_t M, int64_t N, int64_t K, const datr_gemm_epilogue *epi,
+                  float *C, int64_t ldc, float *workspace, int64_t workspace_floats, void *stream);
 
 /* Weight and bias gradient of a 256 -> 256 linear layer over M rows (the MSDeformAttn value /
  * output projections and enc_output over all encoder tokens; autograd's `dy.t().mm(x)` and

@@ -60,29 +60,6 @@ def test_scale_shift_cache_invalidates_on_load():
     torch.testing.assert_close(s2, torch.full((4,), 2.0, device="cuda") / (1 + 1e-5) ** 0.5)
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 13, 21, 48), (1, 256, 25, 42, 128), (3, 16, 7, 5, 1),
-                                   (2, 128, 50, 84, 128)])
-@pytest.mark.parametrize("slope", [0.2, 1.0])
-def test_conv3x3_lrelu(shape, slope):
-    """MFMA implicit-GEMM conv3x3 (+bias +LeakyReLU) vs conv2d + leaky_relu in fp32
-    (/root/reference/models/dino/DA_utils.py:69-79).  Tolerance 1e-4·max|y|: both sides are
-    fp32 sums of 9·Cin products in different orders."""
-    import torch.nn.functional as F
-    from datr_amd.fused import conv3x3_lrelu
-    N, Cin, H, W, Cout = shape
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(Cin + H)
-    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dev)
-    b = torch.randn(Cout, generator=g).to(dev)
-    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), slope)
-    out = conv3x3_lrelu(x, w, b, slope=slope)
-    assert (out.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
-    neg = conv3x3_lrelu(x, w, None, slope=slope, out_scale=-1.0)
-    ref2 = -F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=1), slope)
-    assert (neg.double() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
-
-
 @pytest.mark.parametrize("rows,d,dff", [(1000, 256, 2048), (37, 64, 128), (2200, 256, 1024), (1, 32, 64)])
 def test_ffn_relu_matches_autograd(rows, d, dff):
     """Fused FFN (bias+ReLU GEMM epilogue forward; in-place relu-backward + bias-gradient pass
@@ -165,55 +142,6 @@ def test_fast_linear_matches_autograd(rows, cin, cout):
     assert float((got[3] - ref[3]).abs().max()) <= 2e-5 * scale
     with torch.no_grad():
         assert torch.equal(lin(x), yr.detach())
-
-
-@pytest.mark.parametrize("shape", [(2, 32, 13, 21, 128), (1, 256, 25, 42, 128), (3, 16, 7, 5, 256),
-                                   (2, 128, 50, 84, 128)])
-@pytest.mark.parametrize("slope", [0.2, 1.0])
-def test_conv3x3_lrelu_nhwc(shape, slope):
-    """NHWC MFMA conv3x3 (+bias +LeakyReLU) vs conv2d + leaky_relu
-    (/root/reference/models/dino/DA_utils.py:69-79); ragged tiles, several channel chunks."""
-    import torch.nn.functional as F
-    from datr_amd.fused import conv3x3_lrelu_nhwc
-    N, Cin, H, W, Cout = shape
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(Cin + H)
-    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dev)
-    b = torch.randn(Cout, generator=g).to(dev)
-    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), slope)
-    out = conv3x3_lrelu_nhwc(x, w, b, slope=slope)
-    assert out.is_contiguous(memory_format=torch.channels_last)
-    assert (out.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
-    neg = conv3x3_lrelu_nhwc(x, w, None, slope=slope, out_scale=-1.0)
-    ref2 = -F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=1), slope)
-    assert (neg.double() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
-
-
-@pytest.mark.parametrize("M,N,mode", [(1000, 256, "fwd"), (4129, 384, "fwd"), (2050, 256, "dgrad"), (31, 128, "fwd")])
-def test_gemm_k256_matches_float64(M, N, mode):
-    """Experimental tall-skinny K=256 MFMA GEMM (csrc/gemm_k256.hip) against a float64 product;
-    ragged M (not a multiple of 32) and every column slice."""
-    from datr_amd import _native
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device="cpu").manual_seed(M + N)
-    x = torch.randn(M, 256, generator=g).to(dev)
-    if mode == "fwd":
-        w = (torch.randn(N, 256, generator=g) * 0.05).to(dev)
-        bias = torch.randn(N, generator=g).to(dev)
-        exact = x.double() @ w.double().t() + bias.double()
-        ldk, ldn = 1, 256
-    else:
-        w = (torch.randn(256, N, generator=g) * 0.05).to(dev)
-        bias = None
-        exact = x.double() @ w.double()
-        ldk, ldn = N, 1
-    y = torch.full((M, N), float("nan"), device=dev)
-    rc = _native.lib.datr_gemm_k256_f32(x.data_ptr(), w.data_ptr(), ldk, ldn,
-                                        0 if bias is None else bias.data_ptr(), M, N, y.data_ptr(),
-                                        _native.current_stream_ptr(dev))
-    _native.check(rc, "gemm_k256")
-    torch.testing.assert_close(y.double(), exact, rtol=1e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize("M", [16384, 20001, 88892])

@@ -82,16 +82,21 @@ def test_nhwc_step_with_reference_selection_matches_elementwise(monkeypatch):
     Winograd/MFMA kernel (every width here: the routing cap is lifted), the input_proj norms through
     the NHWC GroupNorm kernels and the discriminator through its Winograd path without any layout
     copy -- against the golden step of the reference."""
-    from datr_amd import domain, fused, strided, wino
+    from datr_amd import bottleneck, domain, fused, strided, wino
     dev = torch.device("cuda:0")
     g = load_npz("model_step.npz")
     _, model, criterion, _ = build_model("cuda:0")
     model.backbone.to(memory_format=torch.channels_last)
     monkeypatch.setattr(wino, "OWN_BACKBONE_3X3_MAX_CH", 1 << 20)
-    calls = {"wino": 0, "gn": 0, "s2": 0, "stem": 0, "even": 0}
+    # the whole-bottleneck nodes on the own GEMM family (datr_amd/bottleneck.py) at this small image too
+    monkeypatch.setattr(bottleneck, "MIN_PIXELS", 1)
+    calls = {"wino": 0, "gn": 0, "s2": 0, "stem": 0, "even": 0, "block": 0}
     real_s2, real_stem, real_even = strided._Conv3x3S2.apply, strided.stem_conv_bn_relu, strided._EvenPixels.apply
+    real_block = bottleneck._BottleneckFn.apply
     monkeypatch.setattr(strided._Conv3x3S2, "apply", lambda *a: (calls.__setitem__("s2", calls["s2"] + 1), real_s2(*a))[1])
     monkeypatch.setattr(strided._EvenPixels, "apply", lambda *a: (calls.__setitem__("even", calls["even"] + 1), real_even(*a))[1])
+    monkeypatch.setattr(bottleneck._BottleneckFn, "apply",
+                        lambda *a: (calls.__setitem__("block", calls["block"] + 1), real_block(*a))[1])
 
     def counted_stem(*a, **k):
         y = real_stem(*a, **k)
@@ -102,15 +107,17 @@ def test_nhwc_step_with_reference_selection_matches_elementwise(monkeypatch):
     monkeypatch.setattr(wino, "wino_conv3x3", lambda *a, **k: (calls.__setitem__("wino", calls["wino"] + 1),
                                                               real_conv(*a, **k))[1])
     monkeypatch.setattr(domain, "wino_conv3x3", wino.wino_conv3x3)
+    monkeypatch.setattr(bottleneck, "wino_conv3x3", wino.wino_conv3x3)
     monkeypatch.setattr(fused._GroupNormNHWC, "apply", lambda *a: (calls.__setitem__("gn", calls["gn"] + 1),
                                                                   real_gn(*a))[1])
     force_reference_selection(model, g, dev)
     out, loss_dict, indices_list, total = run_training_step(model, criterion, dev, g, channels_last=True)
-    # 13 backbone convs + 3 discriminator layers forward; 10 trainable convs + 3 layers backward
-    assert calls["wino"] >= 13 + 3 + 10 + 3 and calls["gn"] == 4, calls
-    # the stride-2 layers: conv2 of layer2-4.0 + input_proj[3] on the tap-list kernels, the three downsample
-    # branches through the even-pixel gather, the frozen stem as one launch (csrc/conv_tap.hip, subsample.hip, stem.hip)
-    assert calls["s2"] == 4 and calls["even"] == 3 and calls["stem"] == 1, calls
+    # all 16 bottlenecks are one node each; inside them 13 stride-1 3x3 convolutions forward + 10 trainable
+    # ones backward on the Winograd kernel, + 3 discriminator layers each way
+    assert calls["block"] == 16 and calls["wino"] >= 13 + 3 + 10 + 3 and calls["gn"] == 4, calls
+    # the stride-2 3x3 / downsample layers of layer2-4.0 run inside their nodes (tap-list kernels, even-pixel
+    # gather); outside remain input_proj[3] on the tap-list kernels and the frozen stem as one launch
+    assert calls["s2"] == 1 and calls["even"] == 0 and calls["stem"] == 1, calls
     check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-3, loss_rtol=2e-3)
     check_gradients(model, g, rtol=3e-2, outlier_fraction=0.05)
 

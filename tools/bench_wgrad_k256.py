@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from datr_amd import fused, tuning  # noqa: E402
-from bench_gemm_k256 import timeit  # noqa: E402
+from bench_gemm import timeit  # noqa: E402
 
 
 def main():
