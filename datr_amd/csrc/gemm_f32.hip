@@ -59,7 +59,7 @@ struct GemmArgs {
     const float *A, *B;
     float *C;                       // output, or the partial buffer [ksplit][M][N] when ksplit > 1
     const float *scale, *shift, *R, *G;
-    float *colpart;                 // [ntm][N] partial column sums, or null
+    float *colpart;                 // [2 ntm][N] partial column sums (one row per row-wave), or null
     int M, N, K;
     int lda, ldb, ldc, ldr, ldg;
     int relu;
@@ -179,6 +179,46 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // ---- epilogue operands: descriptors, and for small tiles the residual OR gate values themselves ----
+    // Everything of the epilogue goes through buffer descriptors whose extent ends behind row M - 1: rows
+    // past the matrix drop out by the range check, a column past N by an out-of-range lane offset.
+    // All workgroups of a CU start together and run in phase, so an epilogue that WAITS for its loads
+    // leaves the matrix pipes idle chip-wide (measured: +75..125 us on the 88 892 x 2048 FFN gradient):
+    // with 1 or 2 accumulator tiles per wave the one extra operand is requested HERE, before the main
+    // loop, and has landed long before the epilogue needs it (16 / 32 registers).
+    const bool raw = a.ksplit > 1;
+    const unsigned c_bytes = (unsigned)a.M * (unsigned)a.ldc * 4u;
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(
+        a.C + (raw ? (size_t)blockIdx.y * (size_t)a.M * (size_t)a.ldc : 0), 0, c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.R ? a.R : a.A), 0, a.R && !raw ? (unsigned)a.M * (unsigned)a.ldr * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.G ? a.G : a.A), 0, a.G && !raw ? (unsigned)a.M * (unsigned)a.ldg * 4u : 0u, 0x00020000);
+    const bool has_r = a.R && !raw, has_g = a.G && !raw, want_cs = a.colpart && !raw;
+    unsigned colb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        colb[j] = n < a.N ? (unsigned)n * 4u : kOutOfRange;
+    }
+    constexpr bool CAN_PRE = TM * TN <= 2;
+    const bool pre_r = CAN_PRE && has_r && !has_g, pre_g = CAN_PRE && has_g && !has_r;
+    float pv[CAN_PRE ? TM * TN * 16 : 1];
+    if (CAN_PRE && (pre_r || pre_g)) {
+        const __amdgpu_buffer_rsrc_t pr = pre_r ? rr : gr;
+        const unsigned pld = (unsigned)(pre_r ? a.ldr : a.ldg) * 4u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lhi;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    pv[CAN_PRE ? (j * TM + i) * 16 + e : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        pr, (int)(colb[j] + (unsigned)(mb + (e & 3) + 8 * (e >> 2)) * pld), 0, 0));
+            }
+    }
+
     if (nk > 0) issue(0);
     for (int kt = 0; kt < nk; ++kt) {
         // the tile of step kt has landed (this wave's share), everybody's share after the barrier; the
@@ -222,34 +262,21 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
     }
 
     // ---- epilogue: 32 lanes = 32 consecutive columns (128 B) of one row; branch-free ---------------
-    // Everything goes through buffer descriptors whose extent ends behind row M - 1: rows past the
-    // matrix drop out by the range check, a column past N by an out-of-range lane offset, and an absent
-    // residual / gate is a zero-length buffer (reads 0) -- the 16 loads of an accumulator tile are issued
-    // back to back, no per-element branches.
-    const bool raw = a.ksplit > 1;
-    const unsigned c_bytes = (unsigned)a.M * (unsigned)a.ldc * 4u;
-    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(
-        a.C + (raw ? (size_t)blockIdx.y * (size_t)a.M * (size_t)a.ldc : 0), 0, c_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.R ? a.R : a.A), 0, a.R && !raw ? (unsigned)a.M * (unsigned)a.ldr * 4u : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.G ? a.G : a.A), 0, a.G && !raw ? (unsigned)a.M * (unsigned)a.ldg * 4u : 0u, 0x00020000);
+    // An absent residual / gate reads as 0; the loads of an accumulator tile that were not requested
+    // before the main loop are issued back to back, no per-element branches.
     const float relu_floor = (a.relu && !raw) ? 0.f : -__builtin_inff();
     const float gate_thr = (a.G && !raw) ? 0.f : -1.f;          // absent gate reads 0 > -1: pass
-    const bool has_r = a.R && !raw, has_g = a.G && !raw, want_cs = a.colpart && !raw;
     float cs[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) cs[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + l31;
-        const bool nin = n < a.N;
         float sc = 1.f, sh = 0.f;
-        if (!raw && nin) {
+        if (!raw && n < a.N) {
             if (a.scale) sc = a.scale[n];
             if (a.shift) sh = a.shift[n];
         }
-        const unsigned colb = nin ? (unsigned)n * 4u : kOutOfRange;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lhi;
@@ -258,23 +285,23 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
 #pragma unroll
             for (int e0 = 0; e0 < 16; e0 += EB) {
                 float rv[EB], gv[EB];
-                if (has_r) {
+                if (has_r && !pre_r) {
 #pragma unroll
                     for (int e = 0; e < EB; ++e)
                         rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rr, (int)(colb + (unsigned)(mb + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2)) * (unsigned)a.ldr * 4u), 0, 0));
+                            rr, (int)(colb[j] + (unsigned)(mb + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2)) * (unsigned)a.ldr * 4u), 0, 0));
                 } else {
 #pragma unroll
-                    for (int e = 0; e < EB; ++e) rv[e] = 0.f;
+                    for (int e = 0; e < EB; ++e) rv[e] = pre_r ? pv[CAN_PRE ? (j * TM + i) * 16 + e0 + e : 0] : 0.f;
                 }
-                if (has_g) {
+                if (has_g && !pre_g) {
 #pragma unroll
                     for (int e = 0; e < EB; ++e)
                         gv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            gr, (int)(colb + (unsigned)(mb + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2)) * (unsigned)a.ldg * 4u), 0, 0));
+                            gr, (int)(colb[j] + (unsigned)(mb + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2)) * (unsigned)a.ldg * 4u), 0, 0));
                 } else {
 #pragma unroll
-                    for (int e = 0; e < EB; ++e) gv[e] = 0.f;
+                    for (int e = 0; e < EB; ++e) gv[e] = pre_g ? pv[CAN_PRE ? (j * TM + i) * 16 + e0 + e : 0] : 0.f;
                 }
 #pragma unroll
                 for (int e = 0; e < EB; ++e) {
@@ -284,23 +311,20 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
                     v = gv[e] > gate_thr ? v : 0.f;
                     if (want_cs) cs[j] += m < a.M ? v : 0.f;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), cr,
-                                                          (int)(colb + (unsigned)m * (unsigned)a.ldc * 4u), 0, 0);
+                                                          (int)(colb[j] + (unsigned)m * (unsigned)a.ldc * 4u), 0, 0);
                 }
             }
         }
     }
     if (want_cs) {
-        // column sums of this tile: lane halves by a cross-lane add, the two row-waves through LDS
-        __syncthreads();                                   // the last step's readers are done with LDS
-        lds_f *red = reinterpret_cast<lds_f *>((uintptr_t)0);
+        // column sums of this wave's rows: the lane halves by one cross-lane add; one partial row per
+        // (row tile, row-wave), no barrier -- `gemm_colsum_finish` adds the 2 ntm rows in a fixed order
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float s = cs[j] + __shfl_xor(cs[j], 32);
-            if (lhi == 0) red[wm * BN + wn * TN * 32 + j * 32 + l31] = s;
+            const float sum = cs[j] + __shfl_xor(cs[j], 32);
+            const int n = n0 + wn * TN * 32 + j * 32 + l31;
+            if (lhi == 0 && n < a.N) a.colpart[(size_t)(tile_m * 2 + wm) * a.N + n] = sum;
         }
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.N)
-            a.colpart[(size_t)tile_m * a.N + n0 + tid] = red[tid] + red[BN + tid];
     }
 }
 
@@ -380,23 +404,26 @@ __global__ __launch_bounds__(1024) void gemm_colsum_finish(const float *__restri
 
 struct Plan { int tm, tn, bk, ksplit; };
 
-// Tile and split choice.  Large tiles while they fill the chip several times over; the weight-gradient
-// form splits the reduction until the launch has ~2.5 workgroups per CU.
+// Tile and split choice, from the sweeps of tools/sweep_gemm.py / tools/probes/gemm_tn_sweep.py at the
+// step's shapes (profiles/r04_gemm_sweep.txt): SMALL tiles with many workgroups per CU win on this
+// kernel -- 64 x 128 while that gives >= 4 workgroups per CU, else 64 x 64 (four resident workgroups
+// cover each other's prologue, barrier and epilogue; 128 x 128 at two per CU is 5-8 % slower on the
+// 88 892-row FFN shapes and 15-30 % slower on the 16 800-pixel maps).  The weight-gradient form splits
+// the reduction until the launch has ~2 workgroups per CU (more: the partial-sum traffic shows).
 Plan pick_plan(int form, long M, long N, long K)
 {
-    Plan p{2, 2, 16, 1};
-    if (N <= 64) p.tn = 1;
-    if (M <= 64) p.tm = 1;
+    Plan p{1, 2, 16, 1};
     auto tiles = [&](const Plan &q) { return ((M + 64 * q.tm - 1) / (64 * q.tm)) * ((N + 64 * q.tn - 1) / (64 * q.tn)); };
     if (form == 2) {
+        if (N <= 64) p.tn = 1;
         const long t = tiles(p);
-        long ks = (640 + t - 1) / t;
         const long steps = (K + BK - 1) / BK;
-        ks = std::max(1L, std::min(ks, steps / 4 > 0 ? steps / 4 : 1L));
+        long ks = std::max(1L, 512 / t);
+        ks = std::max(1L, std::min(ks, steps / 2 > 0 ? steps / 2 : 1L));
         p.ksplit = (int)std::min(ks, 1024L);
     } else {
-        if (tiles(p) < 768 && p.tn == 2) p.tn = 1;
-        if (tiles(p) < 768 && p.tm == 2) p.tm = 1;
+        if (N <= 64) { p.tm = 2; p.tn = 1; p.bk = 32; }        // one column tile: tall tiles, full 128-B k-rows
+        else if (tiles(p) < 1024) p.tn = 1;
     }
     if (const char *f = getenv("DATR_GEMM_PLAN")) {            // development: "tm,tn,bk,ksplit" (ksplit 0 = keep)
         int tm = 0, tn = 0, bk = 0, ks = 0;
@@ -446,7 +473,7 @@ extern "C" int64_t datr_gemm_workspace_floats(int form, int64_t M, int64_t N, in
     const Plan p = pick_plan(form, M, N, K);
     int64_t w = 0;
     if (p.ksplit > 1) w += (int64_t)p.ksplit * M * N;
-    if (want_colsum) w += ((M + 64 * p.tm - 1) / (64 * p.tm)) * N;
+    if (want_colsum) w += 2 * ((M + 64 * p.tm - 1) / (64 * p.tm)) * N;
     return w;
 }
 
@@ -497,7 +524,7 @@ extern "C" int datr_gemm_f32(int form, const float *A, int64_t lda, const float 
         partial = ws; ws += need; left -= need;
     }
     if (colsum) {
-        const int64_t need = (int64_t)a.ntm * N;
+        const int64_t need = (int64_t)2 * a.ntm * N;
         if (!ws || left < need) return DATR_EINVAL;
         a.colpart = ws; ws += need; left -= need;
     }
@@ -520,7 +547,7 @@ extern "C" int datr_gemm_f32(int form, const float *A, int64_t lda, const float 
         if (rc != DATR_OK) return rc;
     }
     if (colsum)
-        hipLaunchKernelGGL(gemm_colsum_finish, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, a.colpart, a.ntm,
+        hipLaunchKernelGGL(gemm_colsum_finish, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, a.colpart, 2 * a.ntm,
                            (int)N, colsum);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
