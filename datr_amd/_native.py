@@ -62,6 +62,8 @@ _SIGNATURES = {
     "datr_conv3x3_wino_wgrad_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "datr_zero_rows_f32": [_vp, _vp, _i64, _i64, _vp],
     "datr_ema_update_f32": [_vp, _vp, _i64, ctypes.c_double, _vp],
+    "datr_grad_norm_clip_coef_f32": [_vp, _vp, _i64, ctypes.c_float, _vp, _vp, _vp],
+    "datr_adamw_step_f32": [_vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp],
     "datr_pixel_ops_u8": [_vp, _vp, _i64, _vp, _i64, _vp, _vp],
     "datr_box_blur_u8": [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint32, ctypes.c_uint32, _i64, _vp],
     "datr_groupnorm_nhwc_forward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _vp,
@@ -140,6 +142,8 @@ def _load() -> ctypes.CDLL:
     lib.datr_conv3x3_cout1_partial_floats.argtypes = [_vp, _i64, _i64]
     lib.datr_ema_piece_elements.restype = ctypes.c_int64
     lib.datr_ema_piece_elements.argtypes = []
+    lib.datr_adamw_piece_elements.restype = ctypes.c_int64
+    lib.datr_adamw_piece_elements.argtypes = []
     lib.datr_gemm_workspace_floats.restype = ctypes.c_int64
     lib.datr_gemm_workspace_floats.argtypes = [ctypes.c_int, _i64, _i64, _i64, ctypes.c_int]
     lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64

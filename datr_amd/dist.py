@@ -27,8 +27,13 @@ What this module does instead:
   * xGMI is point-to-point (7 links x ~153 GB/s), so a ring all-reduce is per-link bound:
     fewer, larger buckets amortise launch latency better than DDP's 25 MB default -- the
     default here is 64 MB (3-4 buckets for 191 MB);
-  * parameters that received no gradient in a step (the reference needs
-    find_unused_parameters=True for those) contribute their zero-filled slice -- no graph walk.
+  * parameters that received no gradient on this rank in a step (the reference needs
+    find_unused_parameters=True for those) contribute their zero-filled slice -- no graph walk -- and
+    a flag per parameter ("some rank produced a gradient") is all-reduced with the buckets: DDP leaves
+    the .grad of a GLOBALLY unused parameter None, so AdamW skips it (no weight decay, no moment decay,
+    no step count).  `used_flags()` hands the flags to the own optimizer kernel as a device tensor (no
+    host synchronisation; datr_amd.optim.FusedClipAdamW); `drop_unused_grads()` is the same thing for a
+    stock optimizer (it reads the flags on the host).
 Shared modules (the six aliased detection heads) appear once: parameters are de-duplicated by
 identity, as `nn.Module.parameters()` already does.
 """
@@ -144,6 +149,16 @@ class GradAllReducer:
         self._build(list(reversed(range(len(self.params)))))
         self._arrival: Optional[List[int]] = [] if rebuild else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        # "a gradient was produced" per parameter: filled on the host while the buckets are gathered,
+        # sent to the device without a synchronisation (pinned staging buffers, used in turn: the epoch
+        # functions fetch the previous step's losses every step, so a buffer is free again two steps later),
+        # MAX-reduced over the ranks in finish()
+        n = len(self.params)
+        pin = self.device.type == "cuda"
+        self._used_stage = [torch.zeros(n, dtype=torch.int32, pin_memory=pin) for _ in range(3)]
+        self._used_turn = 0
+        self._used = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._used_work = None
 
     # -- bucket layout --------------------------------------------------------------------------
     def _build(self, order: List[int]):
@@ -222,8 +237,11 @@ class GradAllReducer:
         per step.)  Parameters without a gradient this step keep their zeroed slice.
         `stream`: the stream the copy runs on when gradients may come from another one."""
         dst, src = [], []
+        stage = self._used_stage[self._used_turn]
         for p, v in zip(b.params, b.views):
             g = p.grad
+            if g is not None:
+                stage[self._index[p]] = 1
             if g is not None and g.data_ptr() != v.data_ptr():
                 if g.shape != v.shape or g.dtype != v.dtype or g.device != v.device:
                     g = g.to(device=v.device, dtype=v.dtype).expand_as(v)
@@ -280,6 +298,8 @@ class GradAllReducer:
             for p in b.params:          # autograd then hands over its gradient tensor as it is
                 p.grad = None
         self._next = 0
+        self._used_turn = (self._used_turn + 1) % len(self._used_stage)
+        self._used_stage[self._used_turn].zero_()
 
     def finish(self):
         """Call after backward: launches, in order, the buckets that are still waiting (their
@@ -289,6 +309,10 @@ class GradAllReducer:
         for b in self.buckets[self._next:]:
             self._launch(b)
         self._next = len(self.buckets)
+        # every bucket is gathered: this rank's used flags are complete
+        self._used.copy_(self._used_stage[self._used_turn], non_blocking=True)
+        if self.world > 1 or FORCE_COLLECTIVES:
+            self._used_work = dist.all_reduce(self._used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
@@ -298,10 +322,29 @@ class GradAllReducer:
                 b.event = None
             if self.world > 1 and self._op == dist.ReduceOp.SUM:
                 b.flat.div_(self.world)
+        if self._used_work is not None:
+            self._used_work.wait()
+            self._used_work = None
         if self._arrival is not None:
+            stage = self._used_stage[self._used_turn].clone()
             self._rebuild_from_first_step()
             for b in self.buckets:      # re-home this step's (already reduced) gradients
                 self._gather(b)
+            self._used_stage[self._used_turn].copy_(stage)     # the re-homing saw every kept gradient
+
+    def used_flags(self) -> torch.Tensor:
+        """int32 device tensor, one entry per parameter of `self.params`: 1 = some rank produced a
+        gradient for it in the step `finish()` just closed.  Valid after finish()."""
+        return self._used
+
+    def drop_unused_grads(self):
+        """.grad = None for the parameters NO rank used this step -- what DistributedDataParallel with
+        find_unused_parameters=True leaves behind (/root/reference/main.py:156), so a stock optimizer
+        skips them.  Reads the flags on the host (a synchronisation); the own optimizer kernel takes
+        `used_flags()` instead."""
+        for p, u in zip(self.params, self._used.tolist()):
+            if not u:
+                p.grad = None
 
     def remove(self):
         for h in self._hooks:

@@ -75,10 +75,12 @@ def _backward_and_step(model, optimizer, losses, max_norm, scaler, amp, reducer=
         reducer.zero_grad()
     else:
         optimizer.zero_grad()
+    own_step = hasattr(optimizer, "clip_and_step") and not amp
     if amp:
         scaler.scale(losses).backward()
         if reducer is not None:
             reducer.finish()
+            reducer.drop_unused_grads()
         if max_norm > 0:
             scaler.unscale_(optimizer)
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
@@ -88,6 +90,18 @@ def _backward_and_step(model, optimizer, losses, max_norm, scaler, amp, reducer=
         losses.backward()
         if reducer is not None:
             reducer.finish()
+        if own_step:
+            # clip + AdamW as multi-tensor launches of the own kernels (datr_amd.optim): the clip
+            # coefficient and the reducer's "some rank used this parameter" flags stay on the device
+            used = None
+            if reducer is not None:
+                if getattr(optimizer, "_index", None) is None:
+                    optimizer.set_used_order(reducer.params)
+                used = reducer.used_flags()
+            optimizer.clip_and_step(max_norm, used)
+            return
+        if reducer is not None:
+            reducer.drop_unused_grads()
         if max_norm > 0:
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
         optimizer.step()

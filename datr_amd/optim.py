@@ -1,0 +1,147 @@
+"""AdamW + gradient clipping of the training loop as multi-tensor launches of the own kernels
+(csrc/adamw.hip) -- the counterpart of
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm);  optimizer.step()
+with `torch.optim.AdamW` (/root/reference/engine.py:99-104, /root/reference/main.py:165).
+
+`FusedClipAdamW` IS a `torch.optim.Optimizer` with AdamW's parameter groups and AdamW's state
+(`step`, `exp_avg`, `exp_avg_sq` per parameter: state_dicts load both ways), so schedulers,
+checkpoints and `optimizer.param_groups[0]["lr"]` work as with the stock class.  Its `step()` is
+AdamW's; `clip_and_step(max_norm, used=...)` is the whole tail of a training step:
+  * the global gradient norm by one deterministic two-launch reduction;
+  * the update kernel multiplies every gradient by the clip coefficient -- a DEVICE scalar -- as it
+    reads it: no pass that rewrites the gradients, no host synchronisation;
+  * `used` (int32 device flags, one per parameter in `all_params` order; from
+    `datr_amd.dist.GradAllReducer.used_flags()`): a parameter whose flag is 0 is skipped
+    entirely, as AdamW skips a parameter whose .grad is None -- the semantics of the reference's
+    DistributedDataParallel(find_unused_parameters=True) (main.py:156) for a globally unused parameter.
+The tables of the kernels (pointers, lr, weight decay per tensor; the work list) live on the device
+and are rebuilt only when a pointer or a hyper-parameter changed (with the flat-bucket reducer the
+gradient views are stable, so in steady state a step uploads nothing).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native
+
+_TENSOR_DT = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("step", "<u8"),
+                       ("numel", "<i8"), ("lr", "<f4"), ("weight_decay", "<f4"), ("used_index", "<i4"), ("pad", "<i4")])
+
+
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Same element order in memory (strides of size-1 dimensions do not matter)."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
+def _dense(t: torch.Tensor) -> bool:
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)) \
+        or t.permute(*sorted(range(t.dim()), key=lambda d: -t.stride(d))).is_contiguous()
+
+
+class FusedClipAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        b = {tuple(g["betas"]) + (g["eps"],) for g in self.param_groups}
+        if len(b) != 1:
+            raise ValueError("FusedClipAdamW: betas / eps must be the same in every parameter group")
+        self._tables = None
+        self._index = None          # id(param) -> position in all_params order (the `used` flags' order)
+        self.last_norm = None       # device tensor [2]: gradient norm, clip coefficient of the last clip_and_step
+
+    # -- state -------------------------------------------------------------------------------------
+    def _state_of(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif not (torch.is_tensor(st["step"]) and st["step"].device == p.device and st["step"].dtype == torch.float32):
+            st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=p.device)   # loaded state_dict
+        return st
+
+    def set_used_order(self, params):
+        """The parameter order the `used` flags of clip_and_step refer to."""
+        self._index = {id(p): i for i, p in enumerate(params)}
+
+    def _build(self):
+        """(tables, key): device tables over every parameter that has a gradient, in group order."""
+        piece = int(_native.lib.datr_adamw_piece_elements())
+        rows, pieces, key, dev = [], [], [], None
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                    raise TypeError("FusedClipAdamW: float32 device parameters only")
+                st = self._state_of(p)
+                gr = p.grad
+                if not _dense(p):
+                    raise ValueError("FusedClipAdamW: parameters must be dense")
+                if not _same_layout(gr, p):           # e.g. an NCHW gradient of a channels_last weight: re-lay it out
+                    gr = p.grad = torch.empty_like(p).copy_(gr)
+                for k in ("exp_avg", "exp_avg_sq"):   # moments of a loaded state_dict may carry another layout
+                    if not _same_layout(st[k], p):
+                        st[k] = torch.empty_like(p).copy_(st[k])
+                dev = p.device
+                ui = -1 if self._index is None else self._index.get(id(p), -1)
+                rows.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                             st["step"].data_ptr(), p.numel(), g["lr"], g["weight_decay"], max(ui, 0), 0))
+                pieces += [(len(rows) - 1, off) for off in range(0, p.numel(), piece)]
+        return rows, pieces, dev
+
+    def _tables_for_step(self):
+        rows, pieces, dev = self._build()
+        if not rows:
+            return None
+        key = tuple(rows)
+        t = self._tables
+        if t is None or t["key"] != key:
+            arr = np.array(rows, dtype=_TENSOR_DT)
+            t = self._tables = {
+                "key": key, "n": len(rows), "npieces": len(pieces), "device": dev,
+                "tensors": torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev),
+                "pieces": torch.tensor(pieces, dtype=torch.int64).reshape(-1, 2).to(dev),
+                "partial": torch.empty(len(pieces), dtype=torch.float32, device=dev),
+                "norm_coef": torch.empty(2, dtype=torch.float32, device=dev),
+            }
+        return t
+
+    # -- steps -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def clip_and_step(self, max_norm: float = 0.0, used: torch.Tensor = None):
+        """clip_grad_norm_(max_norm) over this optimizer's parameters (0 = no clipping) + the AdamW step.
+        Returns the device tensor [norm, coefficient] (None without clipping)."""
+        t = self._tables_for_step()
+        if t is None:
+            return None
+        g0 = self.param_groups[0]
+        stream = _native.current_stream_ptr(t["device"])
+        if used is not None:
+            assert self._index is not None, "set_used_order() first"
+            assert used.dtype == torch.int32 and used.is_cuda and used.is_contiguous()
+        with torch.cuda.device(t["device"]):
+            coef = 0
+            if max_norm and max_norm > 0:
+                rc = _native.lib.datr_grad_norm_clip_coef_f32(t["tensors"].data_ptr(), t["pieces"].data_ptr(), t["npieces"],
+                                                              float(max_norm), t["partial"].data_ptr(),
+                                                              t["norm_coef"].data_ptr(), stream)
+                _native.check(rc, "grad_norm_clip_coef")
+                coef = t["norm_coef"].data_ptr() + 4
+            rc = _native.lib.datr_adamw_step_f32(t["tensors"].data_ptr(), t["n"], t["pieces"].data_ptr(), t["npieces"], coef,
+                                                 0 if used is None else used.data_ptr(), g0["betas"][0], g0["betas"][1],
+                                                 g0["eps"], stream)
+            _native.check(rc, "adamw_step")
+        self.last_norm = t["norm_coef"] if coef else None
+        return self.last_norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.clip_and_step(0.0)
+        return loss

@@ -4,7 +4,7 @@ post-processors through the registry, move to the device, gradient synchronisati
 ranks, 'default' parameter groups, AdamW -- with this build's device-side choices made in one
 place: the backbone in NHWC (`torch.channels_last`, the layout MIOpen's fastest fp32 solvers
 and the own conv kernels want), the per-shape library kernel selections of `datr_amd.tuning`,
-PyTorch's single-kernel multi-tensor AdamW (same update rule), and
+clip + AdamW as multi-tensor launches of the own kernels (`datr_amd.optim`, same update rule), and
 `datr_amd.dist.GradAllReducer` in place of `DistributedDataParallel` (main.py:156).
 
 `bench.py`, the GPU tests and the tools under `tools/` all obtain their training state here and
@@ -46,9 +46,13 @@ def build_training(cfg: Optional[argparse.Namespace] = None, device="cuda", *, s
         model.backbone.to(memory_format=torch.channels_last)
     model.train()
     criterion.train()
-    fused = fused_optimizer and device.type == "cuda"
-    optimizer = torch.optim.AdamW(get_param_dict(cfg, model), lr=cfg.lr,
-                                  weight_decay=cfg.weight_decay, fused=fused)
+    if fused_optimizer and device.type == "cuda":
+        # AdamW + the gradient clip as multi-tensor launches of the own kernels (same update rule, same
+        # state_dict; csrc/adamw.hip)
+        from .optim import FusedClipAdamW
+        optimizer = FusedClipAdamW(get_param_dict(cfg, model), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    else:
+        optimizer = torch.optim.AdamW(get_param_dict(cfg, model), lr=cfg.lr, weight_decay=cfg.weight_decay)
     if reducer is None:
         reducer = dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
     red = GradAllReducer(model) if reducer else None

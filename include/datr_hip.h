@@ -382,6 +382,36 @@ int datr_ema_update_f32(const datr_ema_tensor *tensors, const datr_ema_piece *pi
                         double decay, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The optimizer step of the training loop as multi-tensor launches (csrc/adamw.hip):
+ *     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm);  optimizer.step()   (AdamW)
+ * (/root/reference/engine.py:99-104; /root/reference/main.py:165).
+ * `tensors` (device): one entry per parameter WITH a gradient this step -- param / grad / exp_avg /
+ * exp_avg_sq of `numel` contiguous floats (any dense layout, the same for all four), `step` its own
+ * step count (a device float, as torch's capturable / fused AdamW keeps it), its group's lr and
+ * weight_decay, and `used_index`, its position in the optional `used` flag array.  `pieces` (device):
+ * the work list, one entry per datr_adamw_piece_elements() elements of a tensor.
+ * datr_grad_norm_clip_coef_f32: norm_coef[0] = the 2-norm over all gradients (fixed summation order:
+ *   deterministic), norm_coef[1] = min(1, max_norm / (norm + 1e-6)) -- clip_grad_norm_'s coefficient;
+ *   `partial`: npieces floats of scratch.  The gradients themselves are NOT rescaled.
+ * datr_adamw_step_f32: torch's single-tensor AdamW arithmetic in float32 with every gradient multiplied
+ *   by *clip_coef (NULL = 1) as it is read; tensors whose used[used_index] == 0 (used != NULL) are
+ *   skipped entirely -- no decay, no moments, no step count -- as AdamW skips a parameter whose .grad
+ *   is None (the reference's DistributedDataParallel(find_unused_parameters=True), main.py:156, leaves
+ *   a globally unused parameter's .grad None).  Step counts are incremented after the update.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float *param; const float *grad; float *exp_avg; float *exp_avg_sq; float *step;
+    int64_t numel; float lr; float weight_decay; int32_t used_index; int32_t pad_;
+} datr_adamw_tensor;
+typedef struct { int64_t tensor; int64_t offset; } datr_adamw_piece;
+int64_t datr_adamw_piece_elements(void);
+int datr_grad_norm_clip_coef_f32(const datr_adamw_tensor *tensors, const datr_adamw_piece *pieces, int64_t npieces,
+                                 float max_norm, float *partial, float *norm_coef, void *stream);
+int datr_adamw_step_f32(const datr_adamw_tensor *tensors, int64_t ntensors, const datr_adamw_piece *pieces,
+                        int64_t npieces, const float *clip_coef, const int32_t *used, double beta1, double beta2,
+                        double eps, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Photometric ("strong") augmentation of uint8 [H, W, 3] images, bit-exact with Pillow -- the
  * pixel work of the reference's make_coco_strong_transforms (/root/reference/datasets/DAcoco.py:
  * 330-360: torchvision ColorJitter / RandomGrayscale on PIL images = ImageEnhance.Brightness /

@@ -106,6 +106,9 @@ def test_reducer_single_process_views_and_unused():
     assert torch.count_nonzero(model.unused.weight.grad) == 0
     assert torch.count_nonzero(model.sometimes.weight.grad) == 0
     assert torch.count_nonzero(model.shared.weight.grad) > 0
+    names = [n for n, _ in model.named_parameters()]
+    assert [n for n, u in zip(names, red.used_flags().tolist()) if not u] == \
+        ["unused.weight", "unused.bias", "sometimes.weight", "sometimes.bias"]
     # every gradient view starts on a 256-byte boundary of its bucket (the multi-tensor optimizer /
     # norm kernels vectorise only for aligned pointers), also behind the odd-sized [4] biases
     for b in red.buckets:
@@ -153,6 +156,58 @@ def test_reducer_keeps_channels_last_parameter_layout():
     assert any(b.flat.data_ptr() <= w.grad.data_ptr() < b.flat.data_ptr() + 4 * b.numel
                for b in red.buckets)          # still a view into a flat bucket
     torch.optim.AdamW(net.parameters(), lr=1e-3).step()
+
+
+def _unused_worker(rank, world, port, tmp):
+    """DDP(find_unused_parameters=True) semantics (/root/reference/main.py:156): a parameter NO rank used
+    keeps .grad = None, so AdamW skips it (no weight decay, no state); a parameter only rank 0 used gets
+    the average of its gradient and zero.  Compared with a single-process AdamW fed the averaged
+    gradients (None where no rank produced one)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from datr_amd.dist import GradAllReducer, init_distributed
+    from datr_amd.engine import _backward_and_step
+    init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model, ref = Toy(), Toy()
+    ref.load_state_dict(model.state_dict())
+    red = GradAllReducer(model, bucket_mb=0.0005, first_bucket_mb=0.0002)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.1)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.1)
+    for step in range(3):
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 * step + rank))
+        sometimes = rank == 0 and step != 1                 # step 1: `sometimes` is unused on EVERY rank
+        _backward_and_step(model, opt, model(x, sometimes), 0.1, None, False, red)
+        flags = red.used_flags().tolist()
+        names = [n for n, _ in model.named_parameters()]
+        for n, u in zip(names, flags):
+            expect = not n.startswith("unused") and (not n.startswith("sometimes") or step != 1)
+            assert bool(u) == expect, (step, n, u)
+        # single-process reference: average of the ranks' gradients, None where nobody had one
+        ropt.zero_grad()
+        ref(x, sometimes).backward()
+        for q in ref.parameters():
+            have = torch.tensor([0.0 if q.grad is None else 1.0])
+            dist.all_reduce(have)
+            local = torch.zeros_like(q) if q.grad is None else q.grad.clone()
+            dist.all_reduce(local)
+            q.grad = local / world if float(have) > 0 else None
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
+        ropt.step()
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            torch.testing.assert_close(p, q, rtol=1e-6, atol=1e-7, msg=f"step {step} {n}")
+    assert model.unused.weight not in opt.state or not opt.state[model.unused.weight]      # never touched
+    assert float(opt.state[model.sometimes.weight]["step"]) == 2                           # skipped once
+    assert torch.equal(model.unused.weight, ref.unused.weight)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_globally_unused_parameters_keep_no_gradient_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_unused_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
 # ---------------------------------------------------------------------------------------------
