@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_owner_d32(
 
 }  // namespace
 
-extern "C" int datr_internal_msda_bwd_owner_d32(
+DATR_INTERNAL int datr_internal_msda_bwd_owner_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const DatrTiledMeta *tm, int64_t N, int64_t S, int64_t M, int64_t P, int64_t Lq,
     float *grad_value, int64_t grad_value_row_stride, float *grad_loc, float *grad_attn, void *stream)

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "datr_hip.h"
+#include "msda_tiled.h"
 #include "msda_pyr.h"
 
 #ifdef PYR_PROBE
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
 
 }  // namespace
 
-extern "C" int datr_internal_msda_bwd_dots_pyr2_d32(
+DATR_INTERNAL int datr_internal_msda_bwd_dots_pyr2_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
     const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
     int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream);
@@ -612,7 +613,7 @@ static bool bwd_pyr_plan(PyrMeta &pm, const int64_t *shapes_host, const int64_t 
 }
 
 // info[0..2] = {covered, nRy, nRx} of the backward plan (no launch)
-extern "C" int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+DATR_INTERNAL int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const int64_t *level_start_host,
                                                int64_t S, int64_t M, int32_t *info) {
     PyrMeta pm;
     const bool ok = bwd_pyr_plan(pm, shapes_host, level_start_host, 1, S, M, 32, 4, S, 4);
@@ -622,7 +623,7 @@ extern "C" int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const
 
 // Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
 // grad_value must be zero-filled by the caller.
-extern "C" int datr_internal_msda_bwd_pyr_d32(
+DATR_INTERNAL int datr_internal_msda_bwd_pyr_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
     int64_t D, int64_t L, int64_t Lq, int64_t P, const float *envelope_host, float *grad_value,

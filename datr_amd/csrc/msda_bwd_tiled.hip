@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
 
 }  // namespace
 
-extern "C" int datr_internal_msda_bwd_tiled_d32(
+DATR_INTERNAL int datr_internal_msda_bwd_tiled_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const DatrTiledMeta *meta, int64_t N, int64_t S, int64_t M, int64_t P,
     float *grad_value, float *grad_loc, float *grad_attn, void *stream)

@@ -54,6 +54,7 @@
 #include <cstdlib>
 
 #include "datr_hip.h"
+#include "msda_tiled.h"
 #include "msda_pyr.h"
 
 // Development only (tools/probes/pyr_ablate.sh): compile pieces out to see what they cost.
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_pyr_d32(
 }  // namespace
 
 // Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
-extern "C" int datr_internal_msda_fwd_pyr_d32(
+DATR_INTERNAL int datr_internal_msda_fwd_pyr_d32(
     const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
     const int64_t *level_start_host, int64_t N, int64_t S, int64_t M, int64_t D, int64_t L,
     int64_t Lq, int64_t P, float *out, void *stream)

@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "datr_hip.h"
+#include "msda_tiled.h"
 #include "msda_pyr2.h"
 
 // Development only: compile pieces out to see what they cost (results are wrong with a bit set).
@@ -784,7 +785,7 @@ int launch_tpw(const float *value, const float *loc, const float *attn, const Py
 // Plan only (no launch): what the kernel would do for this geometry / envelope.
 // info[0..7] = {covered, nRy, nRx, phases, tasks per wave, workgroups per image, fill KiB per
 // workgroup (head 0), largest window rows of a phase (head 0)}.
-extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+DATR_INTERNAL int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, const int64_t *level_start_host,
                                                 int64_t S, int64_t M, const float *envelope_host,
                                                 Pyr2Meta *pm_out, int32_t *info) {
     Pyr2Envelope env;
@@ -869,7 +870,7 @@ extern "C" int datr_internal_msda_fwd_pyr2_d32(
 // The value-dependent half of the encoder backward: grad_loc / grad_attn (every element written).
 // DATR_EUNSUPPORTED when the forward's plan does not cover the shape (the caller then lets
 // msda_bwd_pyr.hip compute them with its own gathers).
-extern "C" int datr_internal_msda_bwd_dots_pyr2_d32(
+DATR_INTERNAL int datr_internal_msda_bwd_dots_pyr2_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
     const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
     int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream)

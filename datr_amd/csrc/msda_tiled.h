@@ -26,35 +26,45 @@ struct DatrTiledMeta {
     int Lq;
 };
 
-extern "C" int datr_internal_msda_bwd_tiled_d32(
+// Entry points one .hip file of the library calls in another: C linkage, NOT exported from
+// libdatr_hip.so.  The one exception is declared in include/datr_hip_internal.h (a test hook).
+#define DATR_INTERNAL extern "C" __attribute__((visibility("hidden")))
+
+DATR_INTERNAL int datr_internal_msda_bwd_tiled_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const DatrTiledMeta *meta, int64_t N, int64_t S, int64_t M, int64_t P,
     float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
-extern "C" int datr_internal_msda_fwd_pyr_d32(
+DATR_INTERNAL int datr_internal_msda_fwd_pyr_d32(
     const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
     const int64_t *level_start_host, int64_t N, int64_t S, int64_t M, int64_t D, int64_t L,
     int64_t Lq, int64_t P, float *out, void *stream);
 
 // phased all-LDS forward (msda_fwd_pyr2.hip); envelope_host: float[8][4][4] or NULL
-extern "C" int datr_internal_msda_fwd_pyr2_d32(
+extern "C" int datr_internal_msda_fwd_pyr2_d32(   // exported: include/datr_hip_internal.h
+   
     const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
     const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
     int64_t D, int64_t L, int64_t Lq, int64_t P, float *out, void *stream);
 struct Pyr2Meta;
-extern "C" int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+DATR_INTERNAL int datr_internal_msda_fwd_pyr2_plan(const int64_t *shapes_host, const int64_t *level_start_host,
                                                 int64_t S, int64_t M, const float *envelope_host,
                                                 Pyr2Meta *pm_out, int32_t *info);
-extern "C" int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const int64_t *level_start_host,
+DATR_INTERNAL int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, const int64_t *level_start_host,
                                                int64_t S, int64_t M, int32_t *info);
 
-extern "C" int datr_internal_msda_bwd_pyr_d32(
+DATR_INTERNAL int datr_internal_msda_bwd_pyr_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
     int64_t D, int64_t L, int64_t Lq, int64_t P, const float *envelope_host, float *grad_value,
     float *grad_loc, float *grad_attn, void *stream);
 
-extern "C" int datr_internal_msda_bwd_owner_d32(
+DATR_INTERNAL int datr_internal_msda_bwd_dots_pyr2_d32(
+    const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
+    const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream);
+
+DATR_INTERNAL int datr_internal_msda_bwd_owner_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const DatrTiledMeta *meta, int64_t N, int64_t S, int64_t M, int64_t P, int64_t Lq,
     float *grad_value, int64_t grad_value_row_stride, float *grad_loc, float *grad_attn, void *stream);

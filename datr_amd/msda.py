@@ -25,7 +25,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _native
-from .fused import FastLinear, linear as fast_linear
+from .fused import FastLinear, _amp_bwd, _amp_fwd, linear as fast_linear
 
 __all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "MSDeformAttnFunction",
            "MSDeformAttn"]
@@ -129,6 +129,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         attn_weight = attn_weight.to(value.dtype)
     shapes, lsi = _as_int64(spatial_shapes), _as_int64(level_start_index)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    if envelope is not None:                 # read by the planner through a raw pointer
+        import numpy as np
+        envelope = np.ascontiguousarray(envelope, dtype=np.float32)
+        if envelope.shape != (8, 4, 4):
+            raise ValueError(f"offset envelope must be [8, 4, 4], got {envelope.shape}")
     with torch.cuda.device(value.device):
         stream = _native.current_stream_ptr(value.device)
         if sfx == "f32" and D == 32 and Lq == S and L == 4 and P == 4 and PYR_FORWARD and route == 0:
@@ -223,6 +228,11 @@ class MSDeformAttnFunction(Function):
         ctx.route = int(route)
         kw = {"route": ctx.route} if ctx.route else {}
         if envelope is not None:
+            # the planner reads 8 x 4 x 4 float32 values through a raw pointer: normalise once, for both directions
+            import numpy as np
+            envelope = np.ascontiguousarray(envelope, dtype=np.float32)
+            if envelope.shape != (8, 4, 4):
+                raise ValueError(f"offset envelope must be [8, 4, 4], got {envelope.shape}")
             kw["envelope"] = envelope
         output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                         sampling_locations, attention_weights, ctx.im2col_step, **kw)
@@ -280,6 +290,7 @@ class _ValueProjN(Function):
     reduction replaces n - 1 adds over the 91 MB token tensor), ONE weight-gradient GEMM and one column sum."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, memory, slab, *wb):
         n = len(wb) // 2
         ws, bs = wb[:n], wb[n:]
@@ -292,6 +303,7 @@ class _ValueProjN(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, *gs):
         from .fused import column_sums
         memory, *ws = ctx.saved_tensors

@@ -28,6 +28,13 @@ from . import _native
 OWN_STRIDED = os.environ.get("DATR_OWN_CONV_S2", "1") != "0"
 
 
+def _fits_32bit(x: torch.Tensor, channels: int) -> bool:
+    """The kernels index N H W max(Cin, Cout) elements with 32 bits (they return DATR_EUNSUPPORTED beyond
+    2^29): checked HERE so that an oversized batch takes the library path instead of raising mid-forward."""
+    N, _, H, W = x.shape
+    return N * H * W * channels <= 0x1fffffff
+
+
 def _workspace(x_shape, cout: int, device) -> torch.Tensor:
     N, C, H, W = x_shape
     floats = _native.lib.datr_conv3x3s2_workspace_floats(N, H, W, C, cout)
@@ -147,6 +154,8 @@ def conv3x3_s2(x: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: b
     co, ci, kh, kw = w.shape
     if (kh, kw) != (3, 3) or ci != x.shape[1] or ci % 128 or co % 128:
         return None
+    if not _fits_32bit(x, max(ci, co)):
+        return None
     if scale is not None and scale.requires_grad:
         return None
     return _Conv3x3S2.apply(x, w, None if scale is None else scale.contiguous(),
@@ -161,12 +170,12 @@ def conv1x1_s2(x: torch.Tensor, weight: torch.Tensor, bias=None, relu: bool = Fa
     if not (OWN_STRIDED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         return None
-    if x.shape[1] % 4:
+    if x.shape[1] % 4 or not _fits_32bit(x, max(x.shape[1], weight.shape[0])):
         return None
     return pointwise.conv1x1(_EvenPixels.apply(x), weight, bias, relu)
 
 
-_STEM_WEIGHTS = {}
+_STEM_WEIGHTS = {}       # id(weight) -> (weak reference, (version, data pointer), re-laid-out weights)
 
 
 def stem_conv_bn_relu(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor):
@@ -175,17 +184,24 @@ def stem_conv_bn_relu(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shi
     (trainable stem, other shapes / layouts: the caller takes the library path)."""
     if not (OWN_STRIDED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
             and tuple(w.shape) == (64, 3, 7, 7) and not w.requires_grad and not x.requires_grad
-            and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()):
+            and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()
+            and _fits_32bit(x, 64)):
         return None
-    # the re-laid-out frozen weights are cached per tensor OBJECT (weak reference) and version: a
-    # data pointer alone comes back for a different tensor once the first one is freed
-    hit = _STEM_WEIGHTS.get("w")
+    # the re-laid-out frozen weights are cached per tensor OBJECT (weak reference: an id or a data pointer
+    # alone comes back for a different tensor once the first one is freed) and version -- one entry per
+    # stem, so the student and the EMA teacher of the self-training stage, which alternate every step,
+    # both hit
+    hit = _STEM_WEIGHTS.get(id(w))
     if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
         wk = hit[2]
     else:
         # [r][s * 3 + c][co], every filter row padded to 22 k with a zero row
         wk = torch.nn.functional.pad(w.detach().permute(2, 3, 1, 0).reshape(7, 21, 64), (0, 0, 0, 1)).reshape(154, 64).contiguous()
-        _STEM_WEIGHTS["w"] = (weakref.ref(w), (w._version, w.data_ptr()), wk)
+        for k in [k for k, v in _STEM_WEIGHTS.items() if v[0]() is None]:
+            del _STEM_WEIGHTS[k]
+        if len(_STEM_WEIGHTS) >= 8:
+            _STEM_WEIGHTS.clear()
+        _STEM_WEIGHTS[id(w)] = (weakref.ref(w), (w._version, w.data_ptr()), wk)
     N, _, H, W = x.shape
     y = torch.empty((N, 64, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last)

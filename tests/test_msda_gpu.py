@@ -144,9 +144,9 @@ def pyramid_locs(shapes, N, Mh, P, spread, seed):
     ([(33, 50), (17, 25)], 3.0),                       # 2 levels: not covered -> row kernel
 ])
 def test_pyramid_region_forward_matches_oracle(M, O, dev, shapes, spread, monkeypatch):
-    """Encoder calls take csrc/msda_fwd_pyr.hip (coarse-level windows in LDS, level 0 and
-    out-of-window samples from global memory): == oracle, and == the row kernel up to the order
-    of the fp32 sums."""
+    """Encoder calls take the pyramid-region kernels (csrc/msda_fwd_pyr2.hip: every level's window in LDS,
+    out-of-window samples from global memory; csrc/msda_fwd_pyr.hip where no window plan exists): == oracle,
+    and == the row kernel up to the order of the fp32 sums."""
     assert M.PYR_FORWARD
     N, Mh, D, P = 2, 8, 32, 4
     value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, shapes, P, seed=13)
@@ -189,9 +189,9 @@ def test_pyramid_region_forward_full_size_n4_against_oracle(M, O, dev, kind):
 
 @pytest.mark.parametrize("kind", ["ring", "gauss"])
 def test_encoder_backward_full_size_n4_against_oracle(M, O, dev, kind):
-    """The backward launch of the training step's merged encoder pass -- N = 4, Lq = S = 22 223,
-    the pyramid-region sorted-scatter kernel (csrc/msda_bwd_pyr.hip, route 0 of
-    datr_msda_backward_tiled_f32) -- against the C oracle on EVERY element."""
+    """The backward launches of the training step's merged encoder pass -- N = 4, Lq = S = 22 223: the
+    LDS-window dots kernel (msda_bwd_dots_pyr2_d32) + the value-free sorted scatter (csrc/msda_bwd_pyr.hip),
+    route 0 of datr_msda_backward_tiled_f32 -- against the C oracle on EVERY element."""
     N, Mh, D, P = 4, 8, 32, 4
     value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, FULL_SHAPES, P, seed=31)
     S = value.shape[1]

@@ -10,8 +10,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "datr_hip.h")).read()
+def declared_symbols(header="datr_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(datr_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), f"libdatr_hip.so does not export {name}"
+
+
+def test_nothing_undeclared_is_exported():
+    """Every `datr_*` symbol the library exports is declared in one of the two headers (the cross-file
+    entry points inside csrc/ have hidden visibility)."""
+    import subprocess
+    from datr_amd import _native
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("datr_")}
+    declared = set(declared_symbols()) | set(declared_symbols("datr_hip_internal.h"))
+    assert exported - declared == set(), sorted(exported - declared)
+    assert declared - exported == set(), sorted(declared - exported)
 
 
 def test_abi_version_and_strerror():

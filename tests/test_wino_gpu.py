@@ -142,9 +142,9 @@ def test_backbone_bottleneck_routes_conv2_through_the_own_kernel(monkeypatch):
     torch.testing.assert_close(y_own, y_lib, rtol=1e-4, atol=1e-4)
 
 
-def test_wide_bottleneck_takes_library_forward_and_own_weight_gradient(monkeypatch):
-    """A layer3-sized bottleneck (256-channel conv2): forward and data gradient from the library, the
-    weight gradient of conv2 from csrc/wino_wgrad.hip -- same gradients as the all-library block."""
+def test_wide_bottleneck_weight_gradient_in_the_winograd_domain(monkeypatch):
+    """A layer3-sized bottleneck (256-channel conv2) on the per-op path: the weight gradient of conv2 comes
+    from csrc/wino_wgrad.hip (one call) -- same gradients as the all-library block."""
     from datr_amd import backbone, wino
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
