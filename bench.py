@@ -40,7 +40,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
-PMC_RECORD = "r03_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
+PMC_RECORD = "r04_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
+STEP_MFMA_RECORD = "r04_step_mfma.txt"   # in-step matrix-pipe busy per kernel family (committed PMC pass)
 
 
 from datr_amd.training import build_training, run_steps, synthetic_batch  # noqa: E402
@@ -54,7 +55,9 @@ class MsdaTimer:
         from datr_amd import msda
         self.msda = msda
         self.orig = msda.ms_deform_attn_forward
+        self.orig_bwd = msda.ms_deform_attn_backward
         self.events = []
+        self.bwd_events = []
         self.shape = None
         self.phased = None
         self.enabled = False
@@ -76,6 +79,32 @@ class MsdaTimer:
                 return out
             return self.orig(value, shapes, lsi, loc, attn, step, **kw)
         self.msda.ms_deform_attn_forward = timed
+
+        def timed_bwd(value, shapes, lsi, loc, attn, grad_out, step, **kw):
+            if self.enabled and loc.shape[1] == value.shape[1]:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                out = self.orig_bwd(value, shapes, lsi, loc, attn, grad_out, step, **kw)
+                b.record()
+                self.bwd_events.append((a, b))
+                return out
+            return self.orig_bwd(value, shapes, lsi, loc, attn, grad_out, step, **kw)
+        self.msda.ms_deform_attn_backward = timed_bwd
+
+    def backward_result(self):
+        """The encoder calls' backward (two kernels: LDS-window dots + value-free sorted scatter, plus the
+        zero-fill of grad_value): algorithmic bytes of SURVEY.md 8d over the HIP-event time of the call."""
+        if not self.bwd_events or self.shape is None:
+            return None
+        us = [a.elapsed_time(b) * 1e3 for a, b in self.bwd_events]
+        N, S, M, D, K, Lq = self.shape
+        algo = 4 * N * (2 * S * M * D + Lq * (M * D + 2 * M * K * 2 + 2 * M * K))
+        mean_us = sum(us) / len(us)
+        return {"bound": "hbm", "achieved": round(algo / mean_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(algo / mean_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": "msda_bwd_dots_pyr2_d32 + msda_bwd_pyr_d32 (+ grad_value zero-fill): the encoder "
+                          "call's backward, csrc/msda_fwd_pyr2.hip + csrc/msda_bwd_pyr.hip",
+                "launches": len(us), "mean_us": round(mean_us, 2), "algorithmic_bytes": algo}
 
     def result(self):
         if not self.events:
@@ -152,6 +181,95 @@ def msda_rand_roofline(device, shape):
             "mean_us": round(us, 2), "algorithmic_bytes": algo}
 
 
+def msda_trained_like_roofline(device, shape, sigma=2.5):
+    """The same launch shape with offsets a TRAINED encoder plausibly has: every sample at its query's pixel
+    centre + N(0, sigma px) in the sampled level, independently per (query, head, level, point) -- no two
+    queries agree on an offset, unlike the ring initialisation the timed step runs with (where a head's
+    offsets are one constant vector).  Envelope measured from the locations, as OffsetMonitor does in the
+    model.  Forward and backward, HIP events, mean of 10 launches after 3 warm-up launches."""
+    from datr_amd import msda
+    N, S, M, D, K, Lq = shape
+    shapes_l = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    if (M, D, K, Lq) != (8, 32, 16, S) or sum(h * w for h, w in shapes_l) != S:
+        return None
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = torch.tensor(shapes_l, dtype=torch.int64)
+    lsi = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    refs = []
+    for h, w in shapes_l:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0).view(1, S, 1, 1, 1, 2)
+    wh = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+    loc = (ref + torch.randn(N, Lq, M, 4, 4, 2, generator=g) * sigma / wh).contiguous().to(device)
+    value = (torch.rand(N, S, M, D, generator=g) * 0.01).to(device)
+    attn = torch.softmax(torch.randn(N, Lq, M, 16, generator=g), -1).view(N, Lq, M, 4, 4).to(device)
+    go = torch.randn(N, Lq, M * D, generator=g).to(device)
+    shapes, lsi = shapes.to(device), lsi.to(device)
+    env = msda.measure_envelope(loc, shapes)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) * 1e3 / 10
+    fus = timed(lambda: msda.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64, envelope=env))
+    bus = timed(lambda: msda.ms_deform_attn_backward(value, shapes, lsi, loc, attn, go, 64, envelope=env))
+    algo = 4 * N * (S * M * D + Lq * M * K * 3 + Lq * M * D)
+    algo_b = 4 * N * (2 * S * M * D + Lq * (M * D + 2 * M * K * 2 + 2 * M * K))
+    return {"bound": "hbm", "achieved": round(algo / fus / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(algo / fus / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": "the library's pick for the measured envelope (pyramid kernels with wider windows / more phases)",
+            "inputs": f"pixel-centre reference points + N(0, {sigma} px) offsets per (query, head, level, point); "
+                      "stand-alone launches after the timed region",
+            "mean_us": round(fus, 2), "algorithmic_bytes": algo,
+            "backward": {"mean_us": round(bus, 2), "achieved": round(algo_b / bus / 1e3, 1),
+                         "frac": round(algo_b / bus / 1e3 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": algo_b}}
+
+
+def trained_like_step_ms(state, pool, steps, sigma=2.5):
+    """Step time with encoder offsets of a trained-like spread: every encoder layer's `sampling_offsets`
+    gets weights ~ N(0, (sigma / 26)^2) and a zero bias, so that its offsets are ~ N(0, sigma px) and
+    differ from query to query (the encoder's queries src + pos have a norm of ~26 in this model: with the
+    divisor 26 the monitors report ~14 % of the samples beyond 4.5 px, the share N(0, 2.5 px) gives).  The layers' OffsetMonitors are
+    reset, so each measures the new offsets at its first call and routes / sizes windows from its third call
+    on (in a training run the monitors re-measure every 50th call); 12 warm-up steps.  Parameters and
+    monitors are restored / reset afterwards."""
+    from datr_amd import msda
+    enc = [m for n, m in state.model.named_modules()
+           if n.startswith("transformer.encoder.layers.") and n.endswith(".self_attn")]
+    if not enc:
+        return None
+    saved = [(m.sampling_offsets.weight.detach().clone(), m.sampling_offsets.bias.detach().clone()) for m in enc]
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for m in enc:
+            w = m.sampling_offsets.weight
+            w.copy_((torch.randn(w.shape, generator=g) * (sigma / 26.0)).to(w.device))
+            m.sampling_offsets.bias.zero_()
+    try:
+        msda._MONITORS.clear()
+        run_steps(state, [pool[i % len(pool)] for i in range(12)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(state, [pool[i % len(pool)] for i in range(steps)])
+        torch.cuda.synchronize()
+        ms = round((time.perf_counter() - t0) / steps * 1e3, 2)
+        routes = sorted({(mon.route, round(mon.fraction, 3)) for mon in msda._MONITORS.values()})
+        return {"ms_per_step": ms, "steps": steps, "monitor_routes_and_far_fractions": routes}
+    finally:
+        msda._MONITORS.clear()
+        with torch.no_grad():
+            for m, (w, b) in zip(enc, saved):
+                m.sampling_offsets.weight.copy_(w)
+                m.sampling_offsets.bias.copy_(b)
+
+
 def teacher_student_stage(args, device):
     """BASELINE config 5 on one GPU: datr_amd.engine.train_one_epoch_with_self_training (the
     reference's epoch function, engine.py:146-342) on synthetic batches -- EMA teacher forward
@@ -207,20 +325,23 @@ def teacher_student_stage(args, device):
 
 
 def mfma_utilisation(device, rows):
-    """MFMA utilisation of the linears the step spends most of its GEMM time in -- the encoder
-    FFN, [rows, 256] x [256, 2048] and back (54 % of forward FLOPs) -- timed with HIP
-    events on the current stream, after the timed region, against the dense fp32 MFMA peak."""
+    """Matrix-core figures, against the dense fp32 MFMA peak (exact-fp32 `v_mfma_f32_32x32x2_f32`).
+    Headline = the builder's OWN largest MFMA kernel of the step, measured live with HIP events after the
+    timed region: the FFN hidden gradient dz = (dy W2) * [h > 0] + bias sums, [rows, 256] x [256, 2048],
+    one launch of csrc/gemm_f32.hip per encoder layer (6 per step).  Secondary: the library GEMMs of the
+    same FFN (hipBLASLt / rocBLAS) measured the same way, and the in-step matrix-pipe busy figures per
+    kernel family from the committed PMC pass (not measurable inside this process)."""
+    from datr_amd import gemm
     x = torch.randn(rows, 256, device=device)
     w1 = torch.randn(2048, 256, device=device) * 0.05
+    w2 = torch.randn(256, 2048, device=device) * 0.05
     b1 = torch.zeros(2048, device=device)
     h = torch._addmm_activation(b1, x, w1.t(), use_gelu=False)
+    dy = torch.randn(rows, 256, device=device)
     dh = torch.randn_like(h)
-    cases = {"linear1 fwd (bias+ReLU epilogue)": lambda: torch._addmm_activation(b1, x, w1.t(), use_gelu=False),
-             "linear1 dgrad": lambda: dh.mm(w1),
-             "linear1 wgrad": lambda: dh.t().mm(x)}
     flops = 2.0 * rows * 256 * 2048
-    out, total_t = {}, 0.0
-    for name, fn in cases.items():
+
+    def tflops(fn):
         for _ in range(3):
             fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -229,14 +350,22 @@ def mfma_utilisation(device, rows):
             fn()
         b.record()
         b.synchronize()
-        t = a.elapsed_time(b) / 10 * 1e-3
-        total_t += t
-        out[name] = round(flops / t / 1e12, 1)
-    achieved = 3 * flops / total_t / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_FP32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP32_PEAK_TFLOPS, 4),
-            "kernel": f"encoder FFN GEMMs, M={rows} N=2048 K=256 (hipBLASLt/rocBLAS, fp32)",
-            "per_gemm_tflops": out}
+        return flops / (a.elapsed_time(b) / 10 * 1e-3) / 1e12
+    own = tflops(lambda: gemm.gemm_nn(dy, w2, gate=h, colsum=True))
+    own_plain = tflops(lambda: gemm.gemm_nn(dy, w2))
+    lib = {"linear1 fwd (bias+ReLU epilogue)": tflops(lambda: torch._addmm_activation(b1, x, w1.t(), use_gelu=False)),
+           "linear1 dgrad": tflops(lambda: dh.mm(w1)), "linear1 wgrad": tflops(lambda: dh.t().mm(x)),
+           "linear2 dgrad (what the own kernel replaces, without the mask / bias-sum pass)": tflops(lambda: dy.mm(w2))}
+    lib_mean = 3.0 / sum(1.0 / lib[k] for k in list(lib)[:3])
+    out = {"bound": "mfma", "achieved": round(own, 1), "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(own / MFMA_FP32_PEAK_TFLOPS, 4),
+           "kernel": f"gemm_f32_kernel (own, csrc/gemm_f32.hip): FFN hidden gradient with ReLU mask + bias-sum "
+                     f"epilogue, M={rows} N=2048 K=256, measured live",
+           "own_gemm_without_epilogue_tflops": round(own_plain, 1),
+           "library_gemm": {"achieved": round(lib_mean, 1), "frac": round(lib_mean / MFMA_FP32_PEAK_TFLOPS, 4),
+                            "kernel": f"encoder FFN GEMMs, M={rows} N=2048 K=256 (hipBLASLt / rocBLAS, fp32), measured live",
+                            "per_gemm_tflops": {k: round(v, 1) for k, v in lib.items()}}}
+    return out
 
 
 def msda_cpu_ops(gpu_us=None):
@@ -370,6 +499,10 @@ def main():
     ap.add_argument("--padded-steps", type=int, default=4,
                     help="after the timed region, also time this many steps of a batch that "
                          "needs padding (general path: masks, no shape-keyed caches); 0 = skip")
+    ap.add_argument("--trained-like-steps", type=int, default=6,
+                    help="after the timed region (N = 1), also run this many steps with encoder sampling offsets "
+                         "~ N(0, 2.5 px) per query (what a trained encoder plausibly has) and report their "
+                         "time beside the MSDA figures at those offsets; 0 = skip")
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false",
                     help="keep the backbone in NCHW (default: NHWC / torch.channels_last, which "
                          "MIOpen's measured-fastest fp32 solvers want; same arithmetic)")
@@ -416,6 +549,20 @@ def main():
     def batches(n, offset=0):
         return [pool[(offset + i) % len(pool)] for i in range(n)]
 
+    step_marks = []
+
+    def marked(bs):
+        """The batches, with a HIP event recorded on the launch stream at the start of every step and after
+        the last one: consecutive marks are one step of GPU time apart in steady state."""
+        for b_ in bs:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_marks.append(ev)
+            yield b_
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        step_marks.append(ev)
+
     run_steps(state, batches(args.warmup))
 
     def fence():
@@ -426,10 +573,14 @@ def main():
     fence()
     timer.enabled = True
     t0 = time.perf_counter()
-    run_steps(state, batches(args.steps, args.warmup))
+    run_steps(state, marked(batches(args.steps, args.warmup)))
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    per_step = sorted(a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:]))
+
+    def pct(q):
+        return round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 2) if per_step else None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -459,7 +610,10 @@ def main():
                        "images/sec, DINO-4scale R50 + DATR DA branch training step, bs=2/GPU, 1333x800"),
             "value": round(images / elapsed, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "ms_per_step_percentiles": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9),
+                                        "source": "HIP events at every step boundary of the timed region (rank 0)"},
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
             "config": {"workload": ("BASELINE config 2 read literally: DINO-4scale R50 bs=2 1333x800 burn-in "
                                     "step with the DA branch off (2 source images, no target pass) "
@@ -476,17 +630,32 @@ def main():
             "padded_batch_ms_per_step": padded_ms,
             "roofline": roof,
         }
+        line["roofline_backward"] = timer.backward_result()
         if timer.shape is not None:
             line["roofline_rand_locations"] = msda_rand_roofline(device, timer.shape)
+            if world == 1 and not source_only and args.trained_like_steps > 0:
+                line["roofline_trained_like"] = msda_trained_like_roofline(device, timer.shape)
+                timer.enabled = False
+                line["trained_like_offsets_ms_per_step"] = trained_like_step_ms(state, pool, args.trained_like_steps)
             line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
             # the whole step's matrix-pipe utilisation from the committed PMC pass (every launch of
             # five steps), beside the isolated figure above
-            mf = os.path.join(ROOT, "profiles", "r03_step_mfma.txt")
+            mf = os.path.join(ROOT, "profiles", STEP_MFMA_RECORD)
             if os.path.exists(mf):
+                fam = {}
                 for ln in open(mf):
-                    if ln.startswith("all kernels of the run"):
-                        line["mfma"]["in_step_matrix_pipe_busy"] = float(ln.split()[-1].rstrip("%")) / 100.0
-                        line["mfma"]["in_step_source"] = "profiles/r03_step_mfma.txt (PMC SQ_VALU_MFMA_BUSY_CYCLES, tools/pmc_step_mfma.sh)"
+                    if ln.startswith("#") or ln.startswith("family") or not ln.strip():
+                        continue
+                    name = ln[:58].strip()
+                    busy = float(ln.split()[-1].rstrip("%")) / 100.0
+                    if name.startswith("all kernels of the run"):
+                        line["mfma"]["in_step_matrix_pipe_busy"] = busy
+                    else:
+                        fam[name] = busy
+                line["mfma"]["in_step_matrix_pipe_busy_by_family"] = fam
+                line["mfma"]["in_step_source"] = (f"COMMITTED record profiles/{STEP_MFMA_RECORD} (rocprofv3 PMC "
+                                                  "SQ_VALU_MFMA_BUSY_CYCLES of every launch of five steps, "
+                                                  "tools/pmc_step_mfma.sh) -- not measured in this run")
         if world == 1 and not args.no_cpu_baseline and not source_only:
             if dist.is_initialized():       # one-rank RCCL mode: the CPU leg must not see a NCCL group
                 dist.destroy_process_group()
