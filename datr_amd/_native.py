@@ -92,7 +92,7 @@ _SIGNATURES = {
 class GemmEpilogue(ctypes.Structure):
     """`datr_gemm_epilogue` of include/datr_hip.h."""
     _fields_ = [("scale", _vp), ("shift", _vp), ("residual", _vp), ("ldr", _i64), ("gate", _vp), ("ldg", _i64),
-                ("relu", ctypes.c_int), ("colsum", _vp)]
+                ("relu", ctypes.c_int), ("colsum", _vp), ("rowsum_a", _vp)]
 
 
 class WinoLevel(ctypes.Structure):

@@ -60,6 +60,7 @@ struct GemmArgs {
     float *C;                       // output, or the partial buffer [ksplit][M][N] when ksplit > 1
     const float *scale, *shift, *R, *G;
     float *colpart;                 // [2 ntm][N] partial column sums (one row per row-wave), or null
+    float *asum;                    // TN form: [ksplit][M] sums of A over this split's reduction range, or null
     int M, N, K;
     int lda, ldb, ldc, ldr, ldg;
     int relu;
@@ -178,6 +179,12 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // TN form: the sums of A over the reduction axis (= the bias gradient when A is dy) fall out of the A
+    // fragments: a lane holds A[k][m] of its 32 output rows m for half of the k of every step
+    float asum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+    const bool want_asum = AL == 1 && a.asum != nullptr && wn == 0 && tile_n == 0;
 
     // ---- epilogue operands: descriptors, and for small tiles the residual OR gate values themselves ----
     // Everything of the epilogue goes through buffer descriptors whose extent ends behind row M - 1: rows
@@ -258,6 +265,18 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+            if (AL == 1 && want_asum) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
+            }
+        }
+    }
+    if (AL == 1 && want_asum) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float sum = asum[i] + __shfl_xor(asum[i], 32);
+            const int m = m0 + wm * TM * 32 + i * 32 + l31;
+            if (lhi == 0 && m < a.M) a.asum[(size_t)blockIdx.y * a.M + m] = sum;
         }
     }
 
@@ -402,6 +421,18 @@ __global__ __launch_bounds__(1024) void gemm_colsum_finish(const float *__restri
     }
 }
 
+// out[m] = sum_z part[z][m]  (fixed order)
+__global__ __launch_bounds__(256) void gemm_asum_fold(const float *__restrict__ part, int ksplit, int M, float *__restrict__ out)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s0 = 0.f, s1 = 0.f;
+    int z = 0;
+    for (; z + 1 < ksplit; z += 2) { s0 += part[(size_t)z * M + m]; s1 += part[(size_t)(z + 1) * M + m]; }
+    if (z < ksplit) s0 += part[(size_t)z * M + m];
+    out[m] = s0 + s1;
+}
+
 struct Plan { int tm, tn, bk, ksplit; };
 
 // Tile and split choice, from the sweeps of tools/sweep_gemm.py / tools/probes/gemm_tn_sweep.py at the
@@ -474,6 +505,7 @@ extern "C" int64_t datr_gemm_workspace_floats(int form, int64_t M, int64_t N, in
     int64_t w = 0;
     if (p.ksplit > 1) w += (int64_t)p.ksplit * M * N;
     if (want_colsum) w += 2 * ((M + 64 * p.tm - 1) / (64 * p.tm)) * N;
+    if (form == 2) w += (int64_t)p.ksplit * M;             // sums of A per split (epilogue.rowsum_a)
     return w;
 }
 
@@ -517,6 +549,8 @@ extern "C" int datr_gemm_f32(int form, const float *A, int64_t lda, const float 
         if ((a.R && M * epi->ldr >= (int64_t)1 << 29) || (a.G && M * epi->ldg >= (int64_t)1 << 29)) return DATR_EUNSUPPORTED;
     }
     if (form == 2 && (a.R || a.G || a.relu || colsum || (epi && epi->shift))) return DATR_EUNSUPPORTED;
+    float *rowsum_a = epi ? epi->rowsum_a : nullptr;
+    if (rowsum_a && form != 2) return DATR_EUNSUPPORTED;
     float *partial = nullptr;
     if (a.ksplit > 1 || rowscale) {
         const int64_t need = (int64_t)a.ksplit * M * N;
@@ -527,6 +561,15 @@ extern "C" int datr_gemm_f32(int form, const float *A, int64_t lda, const float 
         const int64_t need = (int64_t)2 * a.ntm * N;
         if (!ws || left < need) return DATR_EINVAL;
         a.colpart = ws; ws += need; left -= need;
+    }
+    if (rowsum_a) {
+        if (a.ksplit > 1) {
+            const int64_t need = (int64_t)a.ksplit * M;
+            if (!ws || left < need) return DATR_EINVAL;
+            a.asum = ws; ws += need; left -= need;
+        } else {
+            a.asum = rowsum_a;
+        }
     }
     auto launch = [&](const GemmArgs &g) {
         return form == 2 ? launch_form<1, 1>(g, p, st) : form == 1 ? launch_form<0, 1>(g, p, st) : launch_form<0, 0>(g, p, st);
@@ -546,6 +589,8 @@ extern "C" int datr_gemm_f32(int form, const float *A, int64_t lda, const float 
         const int rc = launch(a);
         if (rc != DATR_OK) return rc;
     }
+    if (rowsum_a && a.ksplit > 1)
+        hipLaunchKernelGGL(gemm_asum_fold, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, a.asum, a.ksplit, (int)M, rowsum_a);
     if (colsum)
         hipLaunchKernelGGL(gemm_colsum_finish, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, a.colpart, 2 * a.ntm,
                            (int)N, colsum);

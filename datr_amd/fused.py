@@ -183,6 +183,21 @@ def _ffn_hidden_gradient(dy2: torch.Tensor, w2: torch.Tensor, h: torch.Tensor):
     return dh, db1
 
 
+def _ffn_wgrad(dy2: torch.Tensor, x2: torch.Tensor, want_w: bool, want_b: bool):
+    """(dy2^T x2, column sums of dy2) of an FFN linear.  Many rows (the encoder, 88 892): the library GEMM
+    (124-145 TF/s there) + the column-sum kernel; few rows (the decoder, 4 400): the own split-K kernel, whose
+    A fragments give the bias gradient (the library's pick for [2048, 4400] x [4400, 256] runs 141 us in the
+    step, the own kernel ~50 us)."""
+    if want_w and dy2.shape[0] < FFN_FUSED_DZ_MIN_ROWS and _own_wgrad_applies(dy2, x2):
+        from . import gemm
+        if want_b:
+            return gemm.gemm_tn(dy2, x2, bias_grad=True)
+        return gemm.gemm_tn(dy2, x2), None
+    dw = dy2.t().mm(x2) if want_w else None
+    db = column_sums(dy2) if want_b else None
+    return dw, db
+
+
 class _FFNRelu(Function):
     """y = linear2(relu(linear1(x))) with hand-placed fusion points:
 
@@ -214,10 +229,9 @@ class _FFNRelu(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         need = ctx.needs_input_grad
-        dw2 = dy2.t().mm(h) if need[3] else None
-        db2 = column_sums(dy2) if need[4] else None
+        dw2, db2 = _ffn_wgrad(dy2, h, need[3], need[4])
         dh, db1 = _ffn_hidden_gradient(dy2, w2, h)
-        dw1 = dh.t().mm(x2) if need[1] else None
+        dw1 = _ffn_wgrad(dh, x2, need[1], False)[0]
         dx = dh.mm(w1).view(ctx.shape) if need[0] else None
         return dx, dw1, (db1 if need[2] else None), dw2, db2
 
@@ -337,10 +351,9 @@ class _FFNAddNorm(Function):
                 rows, C, dsum.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream)
         _native.check(rc, "add_layernorm_backward")
         need = ctx.needs_input_grad
-        dw2 = dsum.t().mm(h) if need[3] else None
-        db2 = column_sums(dsum) if need[4] else None
+        dw2, db2 = _ffn_wgrad(dsum, h, need[3], need[4])
         dh, db1 = _ffn_hidden_gradient(dsum, w2, h)
-        dw1 = dh.t().mm(x2) if need[1] else None
+        dw1 = _ffn_wgrad(dh, x2, need[1], False)[0]
         dx = torch.addmm(dsum, dh, w1).view(ctx.shape) if need[0] else None
         return (dx, dw1, db1 if need[2] else None, dw2, db2, dgamma if need[5] else None,
                 dbeta if need[6] else None, None)
@@ -531,9 +544,29 @@ class _LinearFn(Function):
         if need[1] and w.shape == (256, 256) and x2.shape[0] >= WGRAD_K256_MIN_ROWS and x2.is_contiguous():
             dw, db = wgrad_k256(dy2, x2, need[2])        # weight and bias gradient in one pass
             return dx, dw, db
+        if need[1] and _own_wgrad_applies(dy2, x2):
+            # weight gradient as the deterministic split-K product of the own GEMM family; the bias
+            # gradient falls out of its A fragments (no column-sum launches)
+            from . import gemm
+            if need[2]:
+                dw, db = gemm.gemm_tn(dy2, x2, bias_grad=True)
+            else:
+                dw, db = gemm.gemm_tn(dy2, x2), None
+            return dx, dw, db
         dw = dy2.t().mm(x2) if need[1] else None
         db = column_sums(dy2) if need[2] else None
         return dx, dw, db
+
+
+OWN_WGRAD = os.environ.get("DATR_OWN_LINEAR_WGRAD", "1") != "0"
+OWN_WGRAD_MIN_ROWS = int(os.environ.get("DATR_OWN_LINEAR_WGRAD_MIN_ROWS", "1024"))
+
+
+def _own_wgrad_applies(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
+    """dy2 [rows, out], x2 [rows, in]: rows enough to split, feature counts multiples of 4, row-contiguous."""
+    return (OWN_WGRAD and dy2.shape[0] >= OWN_WGRAD_MIN_ROWS and dy2.shape[1] % 4 == 0 and x2.shape[1] % 4 == 0
+            and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0
+            and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:

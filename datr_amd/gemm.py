@@ -37,7 +37,7 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
-def _run(form, A, B, M, N, K, out, scale, shift, residual, gate, relu, colsum):
+def _run(form, A, B, M, N, K, out, scale, shift, residual, gate, relu, colsum, rowsum_a=False):
     dev = A.device
     if out is None:
         out = torch.empty(M, N, device=dev, dtype=torch.float32)
@@ -53,6 +53,8 @@ def _run(form, A, B, M, N, K, out, scale, shift, residual, gate, relu, colsum):
     if colsum:
         cs = torch.empty(N, device=dev, dtype=torch.float32)
     epi.colsum = 0 if cs is None else cs.data_ptr()
+    ra = torch.empty(M, device=dev, dtype=torch.float32) if rowsum_a else None
+    epi.rowsum_a = 0 if ra is None else ra.data_ptr()
     for t in (scale, shift):
         assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
     if residual is not None:
@@ -69,6 +71,8 @@ def _run(form, A, B, M, N, K, out, scale, shift, residual, gate, relu, colsum):
                                        ctypes.addressof(epi), out.data_ptr(), _ld(out),
                                        0 if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), stream)
     _native.check(rc, "gemm_f32")
+    if rowsum_a:
+        return out, ra
     return (out, cs) if colsum else out
 
 
@@ -88,9 +92,10 @@ def gemm_nn(dy, w, *, out=None, scale=None, shift=None, residual=None, gate=None
     return _run(NN, dy, w, M, N, K, out, scale, shift, residual, gate, relu, colsum)
 
 
-def gemm_tn(dy, x, *, out=None, rowscale=None):
-    """dy.T @ x (optionally * rowscale[:, None]): dy [P, M], x [P, N] -> [M, N]; deterministic split over P."""
+def gemm_tn(dy, x, *, out=None, rowscale=None, bias_grad=False):
+    """dy.T @ x (optionally * rowscale[:, None]): dy [P, M], x [P, N] -> [M, N]; deterministic split over P.
+    bias_grad: also return dy.sum(0) ([M]) -- it falls out of the A fragments, no extra pass over dy."""
     P, M = dy.shape
     P2, N = x.shape
     assert P == P2
-    return _run(TN, dy, x, M, N, P, out, rowscale, None, None, None, False, False)
+    return _run(TN, dy, x, M, N, P, out, rowscale, None, None, None, False, False, rowsum_a=bias_grad)

@@ -575,7 +575,7 @@ int datr_sine_embed_f32(const float *pos, const float *dim_t, int64_t rows, int6
  *   NT / NN:  epi(v)[m, n] = gate( relu( v * scale[n] + shift[n] + residual[m, n] ) ),
  *             gate(v) = gate[m, n] > 0 ? v : 0;  colsum[n] = sum_m epi(v)[m, n]  (deterministic)
  *   TN:       epi(v)[m, n] = v * scale[m]   (per-ROW scale: the frozen-BN fold of a weight gradient);
- *             the other fields must be NULL / 0.
+ *             rowsum_a[m] = sum_k A[k, m] (deterministic); the other fields must be NULL / 0.
  * Every epilogue field may be NULL / 0; `epi` itself may be NULL.
  * Constraints: pointers 16-byte aligned, leading dimensions and N multiples of 4 (TN: M too);
  * NT / NN: K % 32 == 0.  Every matrix < 2^31 bytes.  Otherwise DATR_EUNSUPPORTED.
@@ -594,6 +594,8 @@ typedef struct {
     int64_t ldg;
     int relu;
     float *colsum;           /* [N] column sums of the result, or NULL                            */
+    float *rowsum_a;         /* TN only: [M] sums of A over the reduction axis (dy^T 1: the bias   */
+                             /* gradient beside the weight gradient dy^T x), or NULL               */
 } datr_gemm_epilogue;
 int64_t datr_gemm_workspace_floats(int form, int64_t M, int64_t N, int64_t K, int want_colsum);
 int datr_gemm_f32(int form, const float *A, int64_t lda, const float *B, int64_t ldb,

@@ -81,6 +81,11 @@ def test_tn_weight_gradient(P, M, N):
     dws = gemm.gemm_tn(dy, x, rowscale=rs)
     _close(dws, ref * rs.double()[:, None], 5e-6)
     assert torch.equal(dw, gemm.gemm_tn(dy, x))
+    # the bias gradient beside the weight gradient: column sums of dy out of the A fragments
+    dwb, db = gemm.gemm_tn(dy, x, bias_grad=True)
+    assert torch.equal(dwb, dw)
+    _close(db, dy.double().sum(0), 1e-5)
+    assert torch.equal(db, gemm.gemm_tn(dy, x, bias_grad=True)[1])
 
 
 def test_row_slices_and_strided_output():

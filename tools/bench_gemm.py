@@ -42,6 +42,7 @@ FWD = [
     ("l4.0.conv1 1024>512", P3, 512, 1024), ("l4.conv1 2048>512", P4, 512, 2048), ("l4.conv3 512>2048", P4, 2048, 512),
     ("proj0 512>256", P2, 256, 512), ("proj1 1024>256", P3, 256, 1024), ("proj2 2048>256", P4, 256, 2048),
     ("ffn1 256>2048", TOK, 2048, 256), ("ffn2 2048>256", TOK, 256, 2048), ("lin 256>256", TOK, 256, 256),
+    ("lin 256>384", TOK, 384, 256), ("dec_ffn1 256>2048", 4400, 2048, 256), ("dec_lin 256>256", 4400, 256, 256),
 ]
 
 

@@ -33,6 +33,7 @@ def main():
         flops = 2.0 * M * N * K
         forms = {
             "nt": (lambda: gemm.gemm_nt(x, w), lambda: x.mm(w.t())),
+            "nt_bias": (lambda: gemm.gemm_nt(x, w, shift=sc), lambda: torch.addmm(sc, x, w.t())),
             "nn": (lambda: gemm.gemm_nn(dy, w), lambda: dy.mm(w)),
             "tn": (lambda: gemm.gemm_tn(dy, x), lambda: dy.t().mm(x)),
         }
