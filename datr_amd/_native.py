@@ -42,7 +42,6 @@ _SIGNATURES = {
     "datr_normalize_pad_u8_f32": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
     "datr_lsap_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "datr_colsum_f32": [_vp, _i64, _i64, _vp, _vp, _vp],
-    "datr_wgrad_k256_f32": [_vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "datr_msda_prologue_forward_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_msda_prologue_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "datr_mha_forward_d32_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_float, _vp, _vp, _vp],
@@ -146,8 +145,6 @@ def _load() -> ctypes.CDLL:
     lib.datr_adamw_piece_elements.argtypes = []
     lib.datr_gemm_workspace_floats.restype = ctypes.c_int64
     lib.datr_gemm_workspace_floats.argtypes = [ctypes.c_int, _i64, _i64, _i64, ctypes.c_int]
-    lib.datr_wgrad_k256_scratch_floats.restype = ctypes.c_int64
-    lib.datr_wgrad_k256_scratch_floats.argtypes = []
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes

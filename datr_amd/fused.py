@@ -484,39 +484,11 @@ def column_sums(x2: torch.Tensor) -> torch.Tensor:
     return out
 
 
-WGRAD_K256_MIN_ROWS = 16384      # below this the library GEMM + column-sum kernel are as fast
-_wgrad_scratch = {}
-
-
-def wgrad_k256(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True):
-    """(dy^T x, dy.sum(0)) for contiguous [M, 256] device float32 tensors in one pass over both
-    (csrc/wgrad_k256.hip: rows split over one workgroup per CU, 256 x 256 product in registers,
-    deterministic two-stage sum).  The partial-product scratch (67 MB) is allocated once per
-    device and stream."""
-    assert dy.is_cuda and dy.dtype == torch.float32 and x.dtype == torch.float32
-    assert dy.dim() == 2 and dy.shape[1] == 256 and x.shape == dy.shape
-    assert dy.is_contiguous() and x.is_contiguous()
-    stream = _native.current_stream_ptr(dy.device)
-    key = (dy.device, stream)
-    scratch = _wgrad_scratch.get(key)
-    if scratch is None:
-        scratch = torch.empty(_native.lib.datr_wgrad_k256_scratch_floats(), device=dy.device,
-                              dtype=torch.float32)
-        _wgrad_scratch[key] = scratch
-    dw = torch.empty(256, 256, device=dy.device, dtype=torch.float32)
-    db = torch.empty(256, device=dy.device, dtype=torch.float32) if with_bias else None
-    with torch.cuda.device(dy.device):
-        rc = _native.lib.datr_wgrad_k256_f32(dy.data_ptr(), x.data_ptr(), dy.shape[0],
-                                             scratch.data_ptr(), dw.data_ptr(),
-                                             0 if db is None else db.data_ptr(), stream)
-    _native.check(rc, "wgrad_k256")
-    return dw, db
-
-
 class _LinearFn(Function):
-    """y = x W^T + b with the same two GEMMs autograd would run in backward, but the bias gradient
-    from the deterministic column-sum kernel (csrc/ffn.hip) instead of ATen's generic reduction
-    (19 us for a [4400, 256] gradient, 41 us for [88892, 256]; ~90 of them per step)."""
+    """y = x W^T + b.  Backward: the data-gradient GEMM autograd would run; weight AND bias gradient from one
+    launch of the own split-K kernel (datr_amd.gemm.gemm_tn: deterministic, the bias gradient falls out of
+    its A fragments) from 1 024 rows on, below that the library GEMM + the deterministic column-sum kernel
+    (csrc/ffn.hip) instead of ATen's generic reduction."""
 
     @staticmethod
     @_amp_fwd
@@ -541,9 +513,6 @@ class _LinearFn(Function):
             dy2 = dy2.contiguous()
         need = ctx.needs_input_grad
         dx = dy2.mm(w).view(ctx.shape) if need[0] else None
-        if need[1] and w.shape == (256, 256) and x2.shape[0] >= WGRAD_K256_MIN_ROWS and x2.is_contiguous():
-            dw, db = wgrad_k256(dy2, x2, need[2])        # weight and bias gradient in one pass
-            return dx, dw, db
         if need[1] and _own_wgrad_applies(dy2, x2):
             # weight gradient as the deterministic split-K product of the own GEMM family; the bias
             # gradient falls out of its A fragments (no column-sum launches)

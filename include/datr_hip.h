@@ -602,17 +602,6 @@ int datr_gemm_f32(int form, const float *A, int64_t lda, const float *B, int64_t
                   int64_t M, int64_t N, int64_t K, const datr_gemm_epilogue *epi,
                   float *C, int64_t ldc, float *workspace, int64_t workspace_floats, void *stream);
 
-/* Weight and bias gradient of a 256 -> 256 linear layer over M rows (the MSDeformAttn value /
- * output projections and enc_output over all encoder tokens; autograd's `dy.t().mm(x)` and
- * `dy.sum(0)`): dw[256, 256] = dy^T x, db[256] = column sums of dy (db may be NULL).  dy, x:
- * contiguous [M, 256].  The rows are split over one workgroup per CU, partial products go to
- * `scratch` (>= datr_wgrad_k256_scratch_floats() floats, caller-owned, reusable by later calls on
- * the same stream) and are added in a fixed order: deterministic. */
-#define DATR_WGRAD_K256_MAX_BLOCKS 256
-int64_t datr_wgrad_k256_scratch_floats(void);
-int datr_wgrad_k256_f32(const float *dy, const float *x, int64_t M, float *scratch, float *dw,
-                        float *db, void *stream);
-
 /* ------------------------------------------------------------------------------------------
  * Hungarian matching on the device: all of a step's rectangular assignment problems in one
  * launch, indices left on the device (no host synchronisation).  Replaces `C.cpu()` +

@@ -149,24 +149,7 @@ def test_fast_linear_matches_autograd(rows, cin, cout):
         assert torch.equal(lin(x), yr.detach())
 
 
-@pytest.mark.parametrize("M", [16384, 20001, 88892])
-def test_wgrad_k256_matches_float64(M):
-    """Weight + bias gradient of a 256 -> 256 linear in one pass (csrc/wgrad_k256.hip) against a
-    float64 product; odd row counts leave a ragged last workgroup."""
-    from datr_amd import fused
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device="cpu").manual_seed(M)
-    x = torch.randn(M, 256, generator=g).to(dev)
-    dy = (torch.randn(M, 256, generator=g) * 0.1).to(dev)
-    dw, db = fused.wgrad_k256(dy, x)
-    exact_w, exact_b = dy.double().t() @ x.double(), dy.double().sum(0)
-    torch.testing.assert_close(dw.double(), exact_w, rtol=1e-5, atol=1e-5 * float(exact_w.abs().max()))
-    torch.testing.assert_close(db.double(), exact_b, rtol=1e-5, atol=1e-5 * float(exact_b.abs().max()))
-    dw2, none = fused.wgrad_k256(dy, x, with_bias=False)
-    assert none is None and torch.equal(dw, dw2)             # deterministic
-
-
-def test_fast_linear_uses_wgrad_kernel_and_matches_autograd():
+def test_fast_linear_takes_own_weight_gradient_kernel_and_matches_autograd():
     from datr_amd import fused
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
@@ -176,7 +159,7 @@ def test_fast_linear_uses_wgrad_kernel_and_matches_autograd():
     x = torch.randn(2, 9000, 256, device=dev, requires_grad=True)
     xr = x.detach().clone().requires_grad_(True)
     gy = torch.randn(2, 9000, 256, device=dev)
-    assert x.numel() // 256 >= fused.WGRAD_K256_MIN_ROWS
+    assert x.numel() // 256 >= fused.OWN_WGRAD_MIN_ROWS
     lin(x).backward(gy)
     ref(xr).backward(gy)
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)

@@ -12,7 +12,6 @@ FAMILIES = [
     ("own stride-2 / stem", ("tap_", "stem_conv", "even_pixels")),
     ("own MSDA", ("msda_", "prologue_", "owner_")),
     ("own attention", ("mha_",)),
-    ("own wgrad_k256", ("wgrad_k256",)),
     ("own LN / GN / affine / ffn / addn / colsum", ("add_ln", "gn_", "affine_", "relu_bwd_bias", "add_n_kernel", "colsum")),
     ("own criterion / matcher / misc", ("focal", "box_loss", "match_cost", "lsap", "topk", "sine_embed", "nms", "ema_", "conv_c1", "c1_", "cout1", "zero_rows")),
     ("ATen / rocclr", ("at::", "__amd_rocclr", "rocclr")),

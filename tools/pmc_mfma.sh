@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/pmc_mfma}
 export TMPDIR=/tmp
 mkdir -p "$OUT" /tmp/pmcm
 for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE; do
-  for P in tools/probes/mha_probe.py tools/bench_wgrad_k256.py; do
+  for P in tools/probes/mha_probe.py; do
     T=$(basename $P .py)
     rm -rf /tmp/pmcm/$C.$T
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcm/$C.$T -o run -- \
@@ -21,7 +21,7 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     if r.get("Counter_Name") != name: continue
     k = r["Kernel_Name"]
-    if "mha_fwd" not in k and "wgrad_k256_kernel" not in k: continue
+    if "mha_fwd" not in k: continue
     agg[k[:60]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print(f"{name} kernel={k} launches={len(v)} mean={sum(v)/len(v):.5g}")

@@ -26,7 +26,7 @@ def family(n):
     if n.startswith("Cijk_"): return "hipBLASLt / rocBLAS GEMMs"
     if "wino_wgrad_nhwc" in n: return "own Winograd weight gradient (wino_wgrad.hip)"
     if "wino_conv" in n: return "own Winograd convolutions (wino.hip)"
-    if "wgrad_k256" in n: return "own 256x256 weight gradient (wgrad_k256.hip)"
+    if "gemm_f32_kernel" in n: return "own GEMM family (gemm_f32.hip: 1x1 convs, FFN dz, weight gradients)"
     if "tap_wgrad(" in n: return "own stride-2 weight gradient (conv_tap.hip)"
     if "tap_conv" in n: return "own stride-2 convolutions fwd + dgrad (conv_tap.hip)"
     if "stem_conv" in n: return "own stem convolution (stem.hip)"
