@@ -296,7 +296,13 @@ class _ValueProjN(Function):
         ws, bs = wb[:n], wb[n:]
         C = memory.shape[-1]
         m2 = memory.reshape(-1, C)
-        outs = tuple(torch.addmm(b, m2, w.t()).view(*memory.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
+        if m2.shape[0] >= 16384 and m2.is_contiguous() and C % 32 == 0 and all(w.shape[0] % 4 == 0 and w.is_contiguous() for w in ws):
+            # own MFMA GEMM with the bias in the epilogue (csrc/gemm_f32.hip): 111 us per projection at the
+            # step's 88 892 rows against 147 us for the library's pick for this call
+            from . import gemm
+            outs = tuple(gemm.gemm_nt(m2, w, shift=b.contiguous()).view(*memory.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
+        else:
+            outs = tuple(torch.addmm(b, m2, w.t()).view(*memory.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
         ctx.save_for_backward(memory, *ws)
         ctx.slab, ctx.n = slab, n
         return outs
