@@ -351,9 +351,23 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
 // A workgroup = 64 float4 columns x 4 slices of z: a thread adds every fourth partial (loads in
 // flight four deep), the four slices meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void gemm_splitk_fold(const float *__restrict__ partial, int ksplit, long mn, int N,
-                                                        const float *__restrict__ rowscale, float *__restrict__ C, int ldc)
+                                                        const float *__restrict__ rowscale, float *__restrict__ C, int ldc,
+                                                        int fold_blocks, const float *__restrict__ asum_part, int M,
+                                                        float *__restrict__ asum_out)
 {
     __shared__ float4 red[3][64];
+    if ((int)blockIdx.x >= fold_blocks) {
+        // the blocks behind the product's: asum_out[m] = sum_z asum_part[z][m] (the bias gradient), fixed order
+        const int m = ((int)blockIdx.x - fold_blocks) * 256 + threadIdx.x;
+        if (m < M) {
+            float s0 = 0.f, s1 = 0.f;
+            int z = 0;
+            for (; z + 1 < ksplit; z += 2) { s0 += asum_part[(size_t)z * M + m]; s1 += asum_part[(size_t)(z + 1) * M + m]; }
+            if (z < ksplit) s0 += asum_part[(size_t)z * M + m];
+            asum_out[m] = s0 + s1;
+        }
+        return;
+    }
     const int c = threadIdx.x & 63, zs = threadIdx.x >> 6;
     const long i4 = (long)blockIdx.x * 64 + c;
     const bool in = i4 * 4 < mn;
@@ -419,18 +433,6 @@ __global__ __launch_bounds__(1024) void gemm_colsum_finish(const float *__restri
         const int nn = ((int)blockIdx.x * 16 + cc) * 4 + k;
         if (nn < N) out[nn] = acc;
     }
-}
-
-// out[m] = sum_z part[z][m]  (fixed order)
-__global__ __launch_bounds__(256) void gemm_asum_fold(const float *__restrict__ part, int ksplit, int M, float *__restrict__ out)
-{
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    float s0 = 0.f, s1 = 0.f;
-    int z = 0;
-    for (; z + 1 < ksplit; z += 2) { s0 += part[(size_t)z * M + m]; s1 += part[(size_t)(z + 1) * M + m]; }
-    if (z < ksplit) s0 += part[(size_t)z * M + m];
-    out[m] = s0 + s1;
 }
 
 struct Plan { int tm, tn, bk, ksplit; };
@@ -583,14 +585,15 @@ extern "C" int datr_gemm_f32(int form, const float *A, int64_t lda, const float 
         const int rc = launch(g);
         if (rc != DATR_OK) return rc;
         const long mn = (long)M * N;
-        hipLaunchKernelGGL(gemm_splitk_fold, dim3((unsigned)((mn / 4 + 63) / 64)), dim3(256), 0, st, partial,
-                           a.ksplit, mn, (int)N, rowscale, C, (int)ldc);
+        const int fold_blocks = (int)((mn / 4 + 63) / 64);
+        const bool fold_asum = rowsum_a && a.ksplit > 1;
+        hipLaunchKernelGGL(gemm_splitk_fold, dim3((unsigned)(fold_blocks + (fold_asum ? (M + 255) / 256 : 0))), dim3(256), 0, st,
+                           partial, a.ksplit, mn, (int)N, rowscale, C, (int)ldc, fold_blocks,
+                           fold_asum ? a.asum : nullptr, (int)M, rowsum_a);
     } else {
         const int rc = launch(a);
         if (rc != DATR_OK) return rc;
     }
-    if (rowsum_a && a.ksplit > 1)
-        hipLaunchKernelGGL(gemm_asum_fold, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, a.asum, a.ksplit, (int)M, rowsum_a);
     if (colsum)
         hipLaunchKernelGGL(gemm_colsum_finish, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, a.colpart, 2 * a.ntm,
                            (int)N, colsum);

@@ -10,7 +10,7 @@ mkdir -p "$(dirname "$OUT")"
 rm -rf /tmp/pmc_step
 cd /tmp
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
-    -d /tmp/pmc_step -o run -- python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --padded-steps 0 \
+    -d /tmp/pmc_step -o run -- python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --padded-steps 0 --trained-like-steps 0 \
     > /tmp/pmc_step.log 2>&1 || { tail -3 /tmp/pmc_step.log; exit 1; }
 cd $REPO
 python - "$(find /tmp/pmc_step -name '*counter_collection.csv' | head -1)" > "$OUT" <<'PY'
