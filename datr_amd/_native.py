@@ -61,6 +61,8 @@ _SIGNATURES = {
     "datr_conv3x3_wino_wgrad_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "datr_zero_rows_f32": [_vp, _vp, _i64, _i64, _vp],
     "datr_ema_update_f32": [_vp, _vp, _i64, ctypes.c_double, _vp],
+    "datr_refine_boxes_forward_f32": [_vp, _vp, _i64, ctypes.c_float, _vp, _vp],
+    "datr_refine_boxes_backward_f32": [_vp, _vp, _vp, _i64, ctypes.c_float, _vp, _vp, _vp],
     "datr_grad_norm_clip_coef_f32": [_vp, _vp, _i64, ctypes.c_float, _vp, _vp, _vp],
     "datr_adamw_step_f32": [_vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp],
     "datr_pixel_ops_u8": [_vp, _vp, _i64, _vp, _i64, _vp, _vp],

@@ -333,6 +333,9 @@ class _StageOutputs(nn.ModuleDict):
         return out
 
 
+_EMPTY_MASKS = {}     # (batch, (H, W), device) -> all-False padding mask of an unpadded batch
+
+
 class Backbone(nn.Module):
     """ResNet-50 trunk; conv1/bn1/layer1 frozen, layer2-4 trainable (backbone.py:79-81);
     returns {name: NestedTensor(feature, nearest-resized padding mask)}."""
@@ -360,7 +363,16 @@ class Backbone(nn.Module):
         m = tensor_list.mask
         assert m is not None
         for name, x in feats.items():
-            mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
+            if tensor_list.padded is False and m.is_cuda:
+                # no padded pixel (known on the host): the resized mask is all False whatever the size
+                key = (int(m.shape[0]), tuple(x.shape[-2:]), str(m.device))
+                mask = _EMPTY_MASKS.get(key)
+                if mask is None:
+                    if len(_EMPTY_MASKS) >= 32:
+                        _EMPTY_MASKS.clear()
+                    mask = _EMPTY_MASKS[key] = torch.zeros((key[0],) + key[1], dtype=torch.bool, device=m.device)
+            else:
+                mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
             out[name] = NestedTensor(x, mask, tensor_list.padded)
         return out
 

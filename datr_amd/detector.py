@@ -30,7 +30,7 @@ from . import boxes as box_ops
 from .backbone import build_backbone
 from .criterion import SetCriterion
 from .denoising import dn_post_process, prepare_for_cdn
-from .fused import GroupNormNHWC
+from .fused import GroupNormNHWC, refine_boxes
 from .domain import (FCDiscriminator_img, decompose_features, get_prototype_class_wise,
                      grad_reverse)
 from .matcher import build_matcher
@@ -165,7 +165,7 @@ class DINO(nn.Module):
             delta = self.bbox_embed[0](hs_all)
         else:
             delta = torch.stack([h(x) for h, x in zip(self.bbox_embed, hs)])
-        coords = (delta + inverse_sigmoid(torch.stack(list(reference[:-1])))).sigmoid()
+        coords = refine_boxes(delta, torch.stack(list(reference[:-1])))
         if all(m is self.class_embed[0] for m in self.class_embed[:n]):
             classes = self.class_embed[0](hs_all)
         else:

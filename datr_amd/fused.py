@@ -421,6 +421,51 @@ def topk_rows(scores: torch.Tensor, k: int):
     return scores.gather(1, idx) if scores.requires_grad or scores.dtype != torch.float32 else val, idx
 
 
+class _RefineBoxes(Function):
+    """sigmoid(delta + inverse_sigmoid(ref)) as one launch each way (csrc/refine.hip)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, delta, ref, eps):
+        d, r = delta.contiguous(), ref.contiguous()
+        out = torch.empty_like(d)
+        with torch.cuda.device(d.device):
+            rc = _native.lib.datr_refine_boxes_forward_f32(d.data_ptr(), r.data_ptr(), d.numel(), eps, out.data_ptr(),
+                                                           _native.current_stream_ptr(d.device))
+        _native.check(rc, "refine_boxes_forward")
+        ctx.save_for_backward(out, r)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, g):
+        out, r = ctx.saved_tensors
+        g = g.contiguous()
+        dd = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        dr = torch.empty_like(out) if ctx.needs_input_grad[1] else None
+        if dd is None and dr is None:
+            return None, None, None
+        with torch.cuda.device(g.device):
+            rc = _native.lib.datr_refine_boxes_backward_f32(g.data_ptr(), out.data_ptr(), r.data_ptr(), g.numel(), ctx.eps,
+                                                            0 if dd is None else dd.data_ptr(),
+                                                            0 if dr is None else dr.data_ptr(),
+                                                            _native.current_stream_ptr(g.device))
+        _native.check(rc, "refine_boxes_backward")
+        return dd, dr, None
+
+
+def refine_boxes(delta: torch.Tensor, ref: torch.Tensor, eps: float = 1e-3) -> torch.Tensor:
+    """sigmoid(delta + inverse_sigmoid(ref)): the decoder's iterative box refinement
+    (/root/reference/models/dino/deformable_transformer.py:738-744, dino.py:316-322).  Device float32 tensors
+    of one shape take the fused kernel; anything else evaluates the reference's op sequence."""
+    if delta.is_cuda and delta.dtype == torch.float32 and ref.dtype == torch.float32 and delta.shape == ref.shape:
+        return _RefineBoxes.apply(delta, ref, eps)
+    from .nested import inverse_sigmoid
+    return (delta + inverse_sigmoid(ref, eps)).sigmoid()
+
+
 FAN_OUT = os.environ.get("DATR_FAN_OUT", "1") != "0"
 
 
@@ -536,6 +581,58 @@ def _own_wgrad_applies(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
     return (OWN_WGRAD and dy2.shape[0] >= OWN_WGRAD_MIN_ROWS and dy2.shape[1] % 4 == 0 and x2.shape[1] % 4 == 0
             and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
+
+
+class _LinearReluFn(Function):
+    """relu(x W^T + b): bias + ReLU in the GEMM's epilogue (`torch._addmm_activation`, bit-identical to linear
+    followed by relu); backward = the ReLU gate in one pass (csrc/affine_act.hip) + _LinearFn's backward."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, w, b):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        y = torch._addmm_activation(b, x2, w.t(), use_gelu=False)
+        ctx.save_for_backward(x2, w, y)
+        ctx.shape = shape
+        return y.view(*shape[:-1], w.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        cols = w.shape[0]
+        dy2 = dy.reshape(-1, cols)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dz = torch.empty_like(dy2)
+        from .pointwise import _ones
+        with torch.cuda.device(dy2.device):
+            rc = _native.lib.datr_affine_act_backward_f32(dy2.data_ptr(), y.data_ptr(), _ones(cols, dy2.device).data_ptr(),
+                                                          dy2.numel(), cols, 1, 1, dz.data_ptr(), 0,
+                                                          _native.current_stream_ptr(dy2.device))
+        _native.check(rc, "affine_act_backward")
+        need = ctx.needs_input_grad
+        dx = dz.mm(w).view(ctx.shape) if need[0] else None
+        if need[1] and _own_wgrad_applies(dz, x2):
+            from . import gemm
+            if need[2]:
+                dw, db = gemm.gemm_tn(dz, x2, bias_grad=True)
+            else:
+                dw, db = gemm.gemm_tn(dz, x2), None
+            return dx, dw, db
+        dw = dz.t().mm(x2) if need[1] else None
+        db = column_sums(dz) if need[2] else None
+        return dx, dw, db
+
+
+def linear_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """relu(F.linear(x, weight, bias)); device float32 inputs take _LinearReluFn, anything else the two ops."""
+    if x.is_cuda and x.dtype == torch.float32 and bias is not None and weight.shape[0] % 4 == 0 \
+            and x.dim() >= 2 and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
+        return _LinearReluFn.apply(x, weight, bias)
+    return torch.relu(torch.nn.functional.linear(x, weight, bias))
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:

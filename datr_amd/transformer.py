@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .fused import FastLinear
-from .fused import attention_d32, fan_out, layer_norm
+from .fused import attention_d32, fan_out, layer_norm, linear_relu, refine_boxes
 from .fused import linear as fused_linear
 from .msda import MSDeformAttn, value_projections
 from .nested import inverse_sigmoid
@@ -39,13 +39,14 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i < self.num_layers - 1:
-                x = F.relu(x)
+            # hidden layers: linear + ReLU as one node (bias + ReLU in the GEMM epilogue on the device)
+            x = linear_relu(x, layer.weight, layer.bias) if i < self.num_layers - 1 else layer(x)
         return x
 
 
 FUSED_ADD_NORM = __import__("os").environ.get("DATR_FUSED_ADD_NORM", "1") != "0"   # A/B switch
+_REF_POINTS = {}      # (level shapes, batch, device) -> encoder reference points of an unpadded batch
+_UNIT_RATIOS = {}     # (batch, levels, device) -> the all-ones valid ratios of an unpadded batch
 
 
 def _add_norm(x, branch, dropout, norm):
@@ -283,9 +284,18 @@ class TransformerEncoder(nn.Module):
         assert ref_token_index is None
         output = src
         if self.num_layers > 0:
-            reference_points = self.get_reference_points(
-                shapes_list if shapes_list is not None else spatial_shapes, valid_ratios,
-                device=src.device)
+            shp = shapes_list if shapes_list is not None else spatial_shapes
+            if key_padding_mask is None and shapes_list is not None and src.is_cuda and not valid_ratios.requires_grad:
+                # unpadded batch (known on the host): the valid ratios are all 1 and the reference points
+                # depend on the geometry only -- ~40 small launches per step, computed once per shape
+                key = (tuple(shapes_list), int(src.shape[0]), str(src.device))
+                reference_points = _REF_POINTS.get(key)
+                if reference_points is None:
+                    if len(_REF_POINTS) >= 16:
+                        _REF_POINTS.clear()
+                    reference_points = _REF_POINTS[key] = self.get_reference_points(shp, valid_ratios, device=src.device)
+            else:
+                reference_points = self.get_reference_points(shp, valid_ratios, device=src.device)
         # the position table feeds every layer: one alias per layer, one gradient sum
         pos_l = fan_out(pos, len(self.layers)) if (pos is not None and 2 <= len(self.layers) <= 8) else None
         for li, layer in enumerate(self.layers):
@@ -438,8 +448,7 @@ class TransformerDecoder(nn.Module):
                                                           "memory_grad_slot": (batched[1], layer_id)}))
             if self.bbox_embed is not None:
                 # iterative refinement: the next layer starts from this layer's box, detached
-                new_ref = (self.bbox_embed[layer_id](output)
-                           + inverse_sigmoid(reference_points)).sigmoid()
+                new_ref = refine_boxes(self.bbox_embed[layer_id](output), reference_points)
                 reference_points = new_ref.detach()
                 ref_points.append(reference_points if self.use_detached_boxes_dec_out else new_ref)
             intermediate.append(layer_norm(output, self.norm))
@@ -653,7 +662,15 @@ class DeformableTransformer(nn.Module):
         mask_flatten = torch.cat(mask_flatten, 1)
         lvl_pos_embed_flatten = self._level_positions(lvl_pos_embed_flatten)
         spatial_shapes, level_start_index = self._level_meta(shapes_list, src_flatten.device)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        if self.no_padding and src_flatten.is_cuda:
+            # no padded pixel anywhere: valid_W / W = valid_H / H = 1 exactly (get_valid_ratio would compute that
+            # with 9 launches per level)
+            key = (int(src_flatten.shape[0]), len(masks), str(src_flatten.device))
+            valid_ratios = _UNIT_RATIOS.get(key)
+            if valid_ratios is None:
+                valid_ratios = _UNIT_RATIOS[key] = torch.ones(key[0], key[1], 2, dtype=torch.float32, device=src_flatten.device)
+        else:
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         memory, _, _ = self.encoder(src_flatten, pos=lvl_pos_embed_flatten,
                                     level_start_index=level_start_index,
                                     spatial_shapes=spatial_shapes, valid_ratios=valid_ratios,

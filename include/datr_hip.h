@@ -382,6 +382,19 @@ int datr_ema_update_f32(const datr_ema_tensor *tensors, const datr_ema_piece *pi
                         double decay, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Iterative box refinement of the decoder, new_ref = sigmoid(delta + inverse_sigmoid(ref)) with
+ * inverse_sigmoid(x) = log(clamp(x, 0, 1).clamp(min = eps) / (1 - clamp(x, 0, 1)).clamp(min = eps))
+ * (/root/reference/models/dino/deformable_transformer.py:738-744, /root/reference/models/dino/dino.py:316-322,
+ * /root/reference/util/misc.py:587-591), as one element-wise launch each way (csrc/refine.hip).
+ * n contiguous floats.  backward: grad_delta / grad_ref may be NULL (not both); autograd's conventions
+ * (sigmoid' = y (1 - y); clamps pass the gradient inside the closed range).
+ * ------------------------------------------------------------------------------------------ */
+int datr_refine_boxes_forward_f32(const float *delta, const float *ref, int64_t n, float eps, float *out,
+                                  void *stream);
+int datr_refine_boxes_backward_f32(const float *grad_out, const float *out, const float *ref, int64_t n, float eps,
+                                   float *grad_delta, float *grad_ref, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * The optimizer step of the training loop as multi-tensor launches (csrc/adamw.hip):
  *     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm);  optimizer.step()   (AdamW)
  * (/root/reference/engine.py:99-104; /root/reference/main.py:165).

@@ -485,3 +485,51 @@ def test_frozen_bn_act_two_handles_sum_their_gradients_in_the_kernel(nhwc, with_
     torch.testing.assert_close(gx1, gx2, rtol=1e-6, atol=1e-6)
     if with_res:
         torch.testing.assert_close(gr1, gr2, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,ref_grad", [((6, 2, 1100, 4), True), ((1100, 4, 4), False), ((3, 5), True)])
+def test_refine_boxes_matches_the_reference_op_sequence(shape, ref_grad):
+    """sigmoid(delta + inverse_sigmoid(ref)) in one launch (csrc/refine.hip) against the reference's ops
+    (/root/reference/models/dino/deformable_transformer.py:738-744, util/misc.py:587-591) in float64 under
+    autograd, with reference values outside [0, 1], on the clamp thresholds and at the eps bounds."""
+    from datr_amd.fused import refine_boxes
+    from datr_amd.nested import inverse_sigmoid
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    delta = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+    ref = (torch.rand(*shape, generator=g) * 1.2 - 0.1)
+    ref.view(-1)[:6] = torch.tensor([0.0, 1.0, 1e-3, 1 - 1e-3, 5e-4, 0.9997])
+    ref = ref.to(dev).requires_grad_(ref_grad)
+    go = torch.randn(*shape, generator=g).to(dev)
+    out = refine_boxes(delta, ref)
+    out.backward(go)
+    d64, r64 = delta.detach().double().requires_grad_(True), ref.detach().double().requires_grad_(ref_grad)
+    exp = (d64 + inverse_sigmoid(r64)).sigmoid()
+    exp.backward(go.double())
+    torch.testing.assert_close(out.double(), exp, rtol=1e-6, atol=2e-7)                    # float32 kernel vs float64
+    torch.testing.assert_close(delta.grad.double(), d64.grad, rtol=1e-5, atol=1e-6)
+    if ref_grad:
+        # 1 - x near 1e-3 carries a relative float32 rounding error of ~6e-5 (x itself is rounded at 6e-8)
+        scale = float(r64.grad.abs().max())
+        torch.testing.assert_close(ref.grad.double(), r64.grad, rtol=3e-4, atol=1e-6 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(4400, 256, 256), (37, 64, 128), (13200, 256, 256)])
+def test_linear_relu_matches_autograd(rows, cin, cout):
+    """relu(linear(x)) as one node (bias + ReLU epilogue; gate pass + weight / bias gradient backward)."""
+    from datr_amd.fused import linear_relu
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows)
+    lin = torch.nn.Linear(cin, cout).to(dev)
+    x = torch.randn(rows, cin, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(rows, cout, generator=g).to(dev)
+    y = linear_relu(x, lin.weight, lin.bias)
+    y.backward(go)
+    got = [y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    yr = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+    yr.backward(go)
+    assert torch.equal(got[0], yr.detach())
+    for a, b in zip(got[1:], [x.grad, lin.weight.grad, lin.bias.grad]):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 3e-5 * scale
