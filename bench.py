@@ -577,7 +577,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    per_step = sorted(a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:]))
+    per_step_raw = [a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:])]
+    per_step = sorted(per_step_raw)
 
     def pct(q):
         return round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 2) if per_step else None
@@ -612,6 +613,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "ms_per_step_percentiles": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9),
+                                        "max": pct(0.9999),
                                         "source": "HIP events at every step boundary of the timed region (rank 0)"},
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
@@ -627,6 +629,7 @@ def main():
                        "grad_reducer": state.reducer is not None,
                        "rccl_world": dist.get_world_size() if dist.is_initialized() else 1},
             "pairs_per_sec": round(images / elapsed / (1 if source_only else 2), 3),
+            "ms_per_step_each": [round(v, 1) for v in per_step_raw] if os.environ.get("DATR_BENCH_PER_STEP") else None,
             "padded_batch_ms_per_step": padded_ms,
             "roofline": roof,
         }

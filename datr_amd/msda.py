@@ -466,11 +466,14 @@ class OffsetMonitor:
     LAG = 2                 # calls between a measurement and its use
     MARGIN_PX = 0.25
     CLIP_PX = 8.0
+    GRID_PX = 0.25          # envelopes are rounded outward to this grid ...
+    SHRINK_PX = 0.75        # ... and only replaced when they grow, or shrink by at least this much somewhere
 
     def __init__(self, every: int = 50):
         self.every, self.calls, self.route, self.fraction = every, 0, 0, 0.0
         self.envelope = None                     # numpy float32 [8, 4, 4] once measured
         self._pending = None
+        self._host = None
         self._centres = {}
 
     @staticmethod
@@ -485,7 +488,20 @@ class OffsetMonitor:
             self.route = self.route_for(self.fraction)
             if host.numel() == 1 + 128:
                 import numpy as np
-                self.envelope = np.ascontiguousarray(host[1:].numpy().reshape(8, 4, 4).copy())
+                env = host[1:].numpy().reshape(8, 4, 4).copy()
+                # Outward to the 0.25-px grid, and KEEP the current envelope while the new one fits inside it
+                # and is not much tighter: the measurement is a quantile of a random sub-sample, and an
+                # envelope that differs in the last digit is a new plan for the library (a grid search on the
+                # host, possibly another kernel variant's first launch: measured 130 ms for the step that
+                # adopted a re-measured, practically identical envelope).
+                q = self.GRID_PX
+                env[..., 0::2] = np.floor(env[..., 0::2] / q) * q
+                env[..., 1::2] = np.ceil(env[..., 1::2] / q) * q
+                cur = self.envelope
+                if cur is None or not (np.all(env[..., 0::2] >= cur[..., 0::2]) and np.all(env[..., 1::2] <= cur[..., 1::2])
+                                       and np.all(env[..., 0::2] - cur[..., 0::2] < self.SHRINK_PX)
+                                       and np.all(cur[..., 1::2] - env[..., 1::2] < self.SHRINK_PX)):
+                    self.envelope = np.ascontiguousarray(env.astype(np.float32))
             self._pending = None
         return self.route
 
@@ -530,7 +546,9 @@ class OffsetMonitor:
             return
         with torch.no_grad():
             res = self.measure(locations, shapes_host)
-            host = torch.empty(res.numel(), dtype=torch.float32, pin_memory=True)
+            host = self._host if (self._host is not None and self._host.numel() == res.numel()) else None
+            if host is None:                     # pinned allocations are slow: one buffer per monitor
+                host = self._host = torch.empty(res.numel(), dtype=torch.float32, pin_memory=True)
             host.copy_(res, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()

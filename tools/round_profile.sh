@@ -1,11 +1,17 @@
-mkdir -p gpurun_out/r3m
-python -m pytest tests -m gpu -q > gpurun_out/r3m/gputests.log 2>&1; tail -3 gpurun_out/r3m/gputests.log
-python bench.py --steps 50 --warmup 20 > gpurun_out/r3m/bench.log 2>&1; tail -1 gpurun_out/r3m/bench.log > gpurun_out/r3m/bench_line.json; cut -c1-400 gpurun_out/r3m/bench_line.json
-python bench.py --stage source-only --steps 20 --warmup 8 > gpurun_out/r3m/bench_src.log 2>&1; tail -1 gpurun_out/r3m/bench_src.log > gpurun_out/r3m/bench_source_only_line.json; cut -c1-300 gpurun_out/r3m/bench_source_only_line.json
-python bench.py --stage teacher --steps 10 --warmup 4 > gpurun_out/r3m/bench_teacher.log 2>&1; tail -1 gpurun_out/r3m/bench_teacher.log > gpurun_out/r3m/bench_teacher_line.json; cut -c1-300 gpurun_out/r3m/bench_teacher_line.json
-DATR_DIST_FORCE_COLLECTIVES=1 python bench.py --steps 20 --warmup 8 --no-cpu-baseline > gpurun_out/r3m/bench_rccl1.log 2>&1; tail -1 gpurun_out/r3m/bench_rccl1.log > gpurun_out/r3m/bench_line_one_rank_rccl.json; cut -c1-300 gpurun_out/r3m/bench_line_one_rank_rccl.json
+# The round's measurements on one GPU box: GPU tests, bench lines (all stages), steady-state kernel table,
+# in-step matrix-pipe counters, MSDA HBM counters.  usage (GPU box): bash tools/round_profile.sh <outdir>
+OUT=${1:-gpurun_out/r4m}
+mkdir -p $OUT
+python -m pytest tests -m gpu -q > $OUT/gputests.log 2>&1; tail -3 $OUT/gputests.log
+python bench.py --steps 50 --warmup 20 > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log > $OUT/bench_line.json; cut -c1-400 $OUT/bench_line.json
+python bench.py --stage source-only --steps 20 --warmup 8 > $OUT/bench_src.log 2>&1; tail -1 $OUT/bench_src.log > $OUT/bench_source_only_line.json; cut -c1-300 $OUT/bench_source_only_line.json
+python bench.py --stage teacher --steps 10 --warmup 4 > $OUT/bench_teacher.log 2>&1; tail -1 $OUT/bench_teacher.log > $OUT/bench_teacher_line.json; cut -c1-300 $OUT/bench_teacher_line.json
+DATR_DIST_FORCE_COLLECTIVES=1 python bench.py --steps 20 --warmup 8 --no-cpu-baseline --trained-like-steps 0 > $OUT/bench_rccl1.log 2>&1; tail -1 $OUT/bench_rccl1.log > $OUT/bench_line_one_rank_rccl.json; cut -c1-300 $OUT/bench_line_one_rank_rccl.json
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/prof; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o step -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --padded-steps 0 --trained-like-steps 0 > /tmp/prof.log 2>&1
-cd $GRAFT_REPO_ROOT; f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); python tools/kstats.py $f --steps 4 --marker msda_fwd_pyr2 --per-step 6 --out gpurun_out/r3m/step_kernels.csv --top 90 --split msda_fwd_pyr2 --split-out gpurun_out/r3m/msda_fwd_by_grid.csv 2>&1 | tail -4
-s=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); head -41 $s > gpurun_out/r3m/rocprof_kernel_stats_top40.csv
-bash tools/pmc_step_mfma.sh gpurun_out/r3m/step_mfma.txt > /dev/null 2>&1; tail -3 gpurun_out/r3m/step_mfma.txt
-bash tools/pmc_msda_raw.sh gpurun_out/r3m/msda_pmc.json 2>&1 | tail -3
+cd $GRAFT_REPO_ROOT; f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); python tools/kstats.py $f --steps 4 --marker msda_fwd_pyr2 --per-step 6 --out $OUT/step_kernels.csv --top 140 --split msda_fwd_pyr2 --split-out $OUT/msda_fwd_by_grid.csv 2>&1 | tail -4
+python tools/kstats.py $f --steps 4 --marker msda_fwd_pyr2 --per-step 6 --top 1 --split gemm_f32_kernel --split-out $OUT/gemm_by_grid.csv > /dev/null 2>&1
+python tools/kfamilies.py $OUT/step_kernels.csv > $OUT/step_families.txt 2>&1
+python tools/probes/elementwise_audit.py $f 4 > $OUT/elementwise_audit.txt 2>&1
+s=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); head -41 $s > $OUT/rocprof_kernel_stats_top40.csv
+bash tools/pmc_step_mfma.sh $OUT/step_mfma.txt > /dev/null 2>&1; tail -3 $OUT/step_mfma.txt
+bash tools/pmc_msda_raw.sh $OUT/msda_pmc.json 2>&1 | tail -3
