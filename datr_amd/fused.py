@@ -183,6 +183,19 @@ def _ffn_hidden_gradient(dy2: torch.Tensor, w2: torch.Tensor, h: torch.Tensor):
     return dh, db1
 
 
+FFN_OWN_HIDDEN = os.environ.get("DATR_FFN_OWN_HIDDEN", "0") != "0"
+
+
+def _ffn_hidden(x2: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
+    """h = relu(x2 W1^T + b1): the library GEMM with its bias + ReLU epilogue, or (DATR_FFN_OWN_HIDDEN=1, an A/B
+    switch) the own family's NT form with the same epilogue."""
+    if FFN_OWN_HIDDEN and x2.shape[0] >= FFN_FUSED_DZ_MIN_ROWS and x2.is_contiguous() and w1.is_contiguous() \
+            and x2.shape[1] % 32 == 0 and w1.shape[0] % 4 == 0:
+        from . import gemm
+        return gemm.gemm_nt(x2, w1, shift=b1.contiguous(), relu=True)
+    return torch._addmm_activation(b1, x2, w1.t(), use_gelu=False)
+
+
 def _ffn_wgrad(dy2: torch.Tensor, x2: torch.Tensor, want_w: bool, want_b: bool):
     """(dy2^T x2, column sums of dy2) of an FFN linear.  Many rows (the encoder, 88 892): the library GEMM
     (124-145 TF/s there) + the column-sum kernel; few rows (the decoder, 4 400): the own split-K kernel, whose
@@ -317,7 +330,7 @@ class _FFNAddNorm(Function):
         x2 = x.reshape(-1, C)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         rows = x2.shape[0]
-        h = torch._addmm_activation(b1, x2, w1.t(), use_gelu=False)
+        h = _ffn_hidden(x2, w1, b1)
         y = torch.addmm(b2, h, w2.t())
         out = torch.empty_like(x2)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
