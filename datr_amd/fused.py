@@ -716,6 +716,75 @@ class _AttentionD32(Function):
         return dq, dk, dv, None, None
 
 
+class _AttentionQKD32(Function):
+    """_AttentionD32 for a MERGED query / key projection qk [L, N, 2 E] (q = qk[..., :E], k = qk[..., E:]) and
+    v [L, N, E], in any row order the kernels' strides express -- sequence-major or batch-major memory.  The
+    output and the gradients are allocated in the memory order of qk; the gradient of qk comes back as one
+    tensor (no split-backward concatenation)."""
+
+    @staticmethod
+    def _like(ref, width):
+        L, N = ref.shape[:2]
+        if ref.stride(1) > ref.stride(0):                  # batch-major memory behind the [L, N, .] view
+            return torch.empty(N, L, width, device=ref.device, dtype=torch.float32).transpose(0, 1)
+        return torch.empty(L, N, width, device=ref.device, dtype=torch.float32)
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, qk, v, mask, heads):
+        L, N, E = v.shape
+        out = _AttentionQKD32._like(qk, E)
+        lse = torch.empty(N, heads, L, device=qk.device, dtype=torch.float32)
+        strides = (ctypes.c_int64 * 8)(qk.stride(0), qk.stride(1), qk.stride(0), qk.stride(1),
+                                       v.stride(0), v.stride(1), out.stride(0), out.stride(1))
+        with torch.cuda.device(qk.device):
+            rc = _native.lib.datr_mha_forward_d32_f32(
+                qk.data_ptr(), qk.data_ptr() + 4 * E, v.data_ptr(), 0 if mask is None else mask.data_ptr(), L, N,
+                heads, ctypes.addressof(strides), 32 ** -0.5, out.data_ptr(), lse.data_ptr(),
+                _native.current_stream_ptr(qk.device))
+        _native.check(rc, "mha_forward_d32")
+        ctx.save_for_backward(qk, v, out, lse, mask)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, dout):
+        qk, v, out, lse, mask = ctx.saved_tensors
+        L, N, E = v.shape
+        H = ctx.heads
+        if dout.stride(-1) != 1 or dout.stride(0) % 4 or dout.stride(1) % 4:
+            dout = dout.contiguous()
+        dqk = _AttentionQKD32._like(qk, 2 * E)
+        dv = _AttentionQKD32._like(qk, E)
+        delta = torch.empty(N, H, L, device=qk.device, dtype=torch.float32)
+        strides = (ctypes.c_int64 * 16)(qk.stride(0), qk.stride(1), qk.stride(0), qk.stride(1),
+                                        v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+                                        dout.stride(0), dout.stride(1), dqk.stride(0), dqk.stride(1),
+                                        dqk.stride(0), dqk.stride(1), dv.stride(0), dv.stride(1))
+        with torch.cuda.device(qk.device):
+            rc = _native.lib.datr_mha_backward_d32_f32(
+                dout.data_ptr(), qk.data_ptr(), qk.data_ptr() + 4 * E, v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                0 if mask is None else mask.data_ptr(), L, N, H, ctypes.addressof(strides), 32 ** -0.5,
+                delta.data_ptr(), dqk.data_ptr(), dqk.data_ptr() + 4 * E, dv.data_ptr(),
+                _native.current_stream_ptr(qk.device))
+        _native.check(rc, "mha_backward_d32")
+        return dqk, dv, None, None
+
+
+def attention_qk_d32(qk: torch.Tensor, v: torch.Tensor, mask, heads: int) -> torch.Tensor:
+    """attention_d32 with the query and key given as ONE tensor qk [L, N, 2 * heads * 32] (the decoder's merged
+    projection); the [L, N, .] views may sit on batch-major memory (transposed [N, L, .] tensors).  Returns
+    [L, N, heads * 32] in the memory order of qk."""
+    E = heads * 32
+    assert qk.is_cuda and qk.dtype == v.dtype == torch.float32 and qk.shape == (*v.shape[:2], 2 * E) and v.shape[-1] == E
+    assert qk.stride(-1) == v.stride(-1) == 1
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.shape == (qk.shape[0], qk.shape[0]) and mask.is_contiguous()
+    return _AttentionQKD32.apply(qk, v, mask, heads)
+
+
 def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask, heads: int) -> torch.Tensor:
     """softmax(q k^T / sqrt(32) + mask) v per (batch, head) for sequence-first [L, N, heads * 32]
     device float32 tensors (last dim contiguous, other strides multiples of 4 -- column slices of a

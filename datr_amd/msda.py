@@ -438,6 +438,55 @@ def _inverse_wh(spatial_shapes: torch.Tensor, n_heads: int, n_points: int) -> to
     return hit[0]
 
 
+class _StackLinear(torch.autograd.Function):
+    """(w, b) = ([diag(scale) wa ; wb], [scale * ba ; bb]) in one launch (csrc/stack_linear.hip); backward: the
+    gradients of wb / bb (and of wa / ba without a scale) are row slices of the incoming ones, the scaled block
+    takes one launch."""
+
+    @staticmethod
+    def forward(ctx, wa, ba, wb, bb, scale):
+        Ra, C = wa.shape
+        Rb = wb.shape[0]
+        w = torch.empty(Ra + Rb, C, device=wa.device, dtype=torch.float32)
+        b = torch.empty(Ra + Rb, device=wa.device, dtype=torch.float32)
+        with torch.cuda.device(wa.device):
+            rc = _native.lib.datr_stack_linear_forward_f32(
+                wa.data_ptr(), ba.data_ptr(), wb.data_ptr(), bb.data_ptr(), 0 if scale is None else scale.data_ptr(),
+                Ra, Rb, C, w.data_ptr(), b.data_ptr(), _native.current_stream_ptr(wa.device))
+        _native.check(rc, "stack_linear_forward")
+        ctx.scale = scale
+        ctx.Ra = Ra
+        return w, b
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dw, db):
+        Ra, scale = ctx.Ra, ctx.scale
+        dw = dw if dw.is_contiguous() else dw.contiguous()
+        db = db if db.is_contiguous() else db.contiguous()
+        if scale is None:
+            return dw[:Ra], db[:Ra], dw[Ra:], db[Ra:], None
+        dwa = torch.empty(Ra, dw.shape[1], device=dw.device, dtype=torch.float32)
+        dba = torch.empty(Ra, device=dw.device, dtype=torch.float32)
+        with torch.cuda.device(dw.device):
+            rc = _native.lib.datr_stack_linear_backward_f32(dw.data_ptr(), db.data_ptr(), scale.data_ptr(), Ra,
+                                                            dw.shape[1], dwa.data_ptr(), dba.data_ptr(),
+                                                            _native.current_stream_ptr(dw.device))
+        _native.check(rc, "stack_linear_backward")
+        return dwa, dba, dw[Ra:], db[Ra:], None
+
+
+def stack_linear(wa, ba, wb, bb, scale=None):
+    """Weights and biases of two linear layers on the same input, stacked for one GEMM; rows of the first layer
+    optionally scaled (see _StackLinear).  Device float32 contiguous parameters take the one-launch kernel."""
+    if wa.is_cuda and all(t.dtype == torch.float32 and t.is_contiguous() for t in (wa, ba, wb, bb)) \
+            and wa.shape[1] % 4 == 0 and (scale is None or (scale.dtype == torch.float32 and scale.is_contiguous())):
+        return _StackLinear.apply(wa, ba, wb, bb, scale)
+    if scale is not None:
+        wa, ba = wa * scale[:, None], ba * scale
+    return torch.cat([wa, wb], 0), torch.cat([ba, bb], 0)
+
+
 class OffsetMonitor:
     """Watches where an encoder layer's samples fall relative to their queries and steers its MSDA
     calls: the ROUTE (which kernel family) and the ENVELOPE (window sizes of the phased pyramid
@@ -669,16 +718,15 @@ class MSDeformAttn(nn.Module):
             # weight matrices stacked (N = 384 instead of 256 + 128) forward, and one dgrad / one
             # wgrad GEMM backward; the parameters stay separate (state_dict, optimizer)
             w_off, b_off = self.sampling_offsets.weight, self.sampling_offsets.bias
+            inv = None
             if reference_points.shape[-1] == 2:
                 # 2-d reference points (encoder): offsets are divided by (W_l, H_l) per level.
                 # Scaling the 256 rows of the small weight matrix instead folds that division --
                 # and its backward -- into the GEMM: two passes over the [N, Lq, 256] offsets
                 # less per layer and direction.  (q W) s == q (W s) up to fp32 rounding.
                 inv = _inverse_wh(input_spatial_shapes, H, self.n_points)
-                w_off, b_off = w_off * inv[:, None], b_off * inv
                 fold_wh = True
-            w = torch.cat([w_off, self.attention_weights.weight], 0)
-            b = torch.cat([b_off, self.attention_weights.bias], 0)
+            w, b = stack_linear(w_off, b_off, self.attention_weights.weight, self.attention_weights.bias, inv)
             both = fast_linear(query, w, b)
             if FUSED_PROLOGUE and (H, self.n_levels, self.n_points) == (8, 4, 4) \
                     and both.dtype == torch.float32 and not reference_points.requires_grad \

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .fused import FastLinear
-from .fused import attention_d32, fan_out, layer_norm, linear_relu, refine_boxes
+from .fused import attention_qk_d32, fan_out, layer_norm, linear_relu, refine_boxes
 from .fused import linear as fused_linear
 from .msda import MSDeformAttn, value_projections
 from .nested import inverse_sigmoid
@@ -61,6 +61,7 @@ def _add_norm(x, branch, dropout, norm):
 FUSED_FFN = __import__("os").environ.get("DATR_FUSED_FFN", "1") != "0"     # A/B switch
 FUSED_SELF_ATTN = __import__("os").environ.get("DATR_FUSED_SELF_ATTN", "1") != "0"   # A/B switch
 OWN_ATTENTION = __import__("os").environ.get("DATR_OWN_ATTENTION", "1") != "0"       # A/B switch
+BATCH_FIRST_DECODER = __import__("os").environ.get("DATR_BATCH_FIRST_DECODER", "1") != "0"   # A/B switch
 
 
 def _plain_mha(m: nn.MultiheadAttention) -> bool:
@@ -68,38 +69,48 @@ def _plain_mha(m: nn.MultiheadAttention) -> bool:
             and m.bias_k is None and not m.add_zero_attn and not (m.training and m.dropout > 0))
 
 
-def _self_attention(mha: nn.MultiheadAttention, qk_in: Tensor, v_in: Tensor, attn_mask) -> Tensor:
-    """`mha(qk_in, qk_in, v_in, attn_mask=attn_mask, need_weights=False)[0]` for [L, N, E] inputs --
+def _self_attention(mha: nn.MultiheadAttention, qk_in: Tensor, v_in: Tensor, attn_mask, batch_first=False) -> Tensor:
+    """`mha(qk_in, qk_in, v_in, attn_mask=attn_mask, need_weights=False)[0]` for [L, N, E] inputs
+    ([N, L, E] with batch_first: same values, the result in the layout of the inputs) --
     the decoder's self-attention call (deformable_transformer.py:880-884: query = key = tgt + pos,
     value = tgt) -- with the same parameters and the same operations per element, arranged for
     fewer launches: the query and key projections share their input, so they are ONE GEMM
     (nn.MultiheadAttention runs three because value differs); linears go through fused.linear
     (column-sum bias gradients); the in_proj parameters are split, not sliced (one backward
     node).  Scaled dot-product attention itself is the own MFMA kernel pair (csrc/mha_fwd.hip,
-    csrc/mha_bwd.hip) for head_dim 32 in fp32, PyTorch's otherwise."""
-    L, N, E = qk_in.shape
+    csrc/mha_bwd.hip) for head_dim 32 in fp32, PyTorch's otherwise; the kernels take strides, so the
+    merged query / key projection goes in whole and its gradient comes back whole (no split / cat)."""
+    if batch_first:
+        N, L, E = qk_in.shape
+    else:
+        L, N, E = qk_in.shape
     H = mha.num_heads
     hd = E // H
     w_qk, w_v = mha.in_proj_weight.split([2 * E, E], 0)
     b_qk, b_v = mha.in_proj_bias.split([2 * E, E], 0)
-    q, k = fused_linear(qk_in, w_qk, b_qk).split(E, dim=-1)              # [L, N, E] views
+    qk = fused_linear(qk_in, w_qk, b_qk)                                 # layout of the input, 2 E wide
     v = fused_linear(v_in, w_v, b_v)
     if attn_mask is not None and attn_mask.dtype == torch.bool:
-        attn_mask = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device) \
+        attn_mask = torch.zeros(attn_mask.shape, dtype=qk.dtype, device=qk.device) \
             .masked_fill_(attn_mask, float("-inf"))
-    if OWN_ATTENTION and hd == 32 and q.dtype == torch.float32 and all(
-            x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0 for x in (q, k, v)):
-        # own MFMA forward / backward (csrc/mha_fwd.hip, mha_bwd.hip), output already in the [L, N, E]
-        # layout out_proj reads
-        out = attention_d32(q, k, v, None if attn_mask is None else attn_mask.contiguous(), H)
-        out = out.view(L * N, E)
+    if batch_first:
+        qk, v = qk.transpose(0, 1), v.transpose(0, 1)                   # [L, N, .] views of batch-major memory
+    if OWN_ATTENTION and hd == 32 and qk.dtype == torch.float32 and all(
+            x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0 for x in (qk, v)):
+        # own MFMA forward / backward (csrc/mha_fwd.hip, mha_bwd.hip); the output comes in the memory
+        # order of the inputs, i.e. the layout out_proj reads
+        out = attention_qk_d32(qk, v, None if attn_mask is None else attn_mask.contiguous(), H)
+        if batch_first:
+            out = out.transpose(0, 1)
+        out = out.reshape(L * N, E)
     else:
+        q, k = qk.split(E, dim=-1)
         # [L, N, E] -> [N, H, L, hd] (views, as F.multi_head_attention_forward arranges them)
         q, k, v = (x.reshape(L, N * H, hd).transpose(0, 1).reshape(N, H, L, hd) for x in (q, k, v))
         out = F.scaled_dot_product_attention(
             q, k, v, None if attn_mask is None else attn_mask.view(1, 1, L, L), 0.0, False)
-        out = out.permute(2, 0, 1, 3).reshape(L * N, E)
-    return fused_linear(out, mha.out_proj.weight, mha.out_proj.bias).view(L, N, E)
+        out = (out.permute(0, 2, 1, 3) if batch_first else out.permute(2, 0, 1, 3)).reshape(L * N, E)
+    return fused_linear(out, mha.out_proj.weight, mha.out_proj.bias).view(qk_in.shape)
 
 
 def _ffn(x, linear1, activation, dropout, linear2):
@@ -336,37 +347,46 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def forward_ffn(self, tgt):
         return _ffn_block(tgt, self.linear1, self.activation, self.dropout3, self.linear2, self.dropout4, self.norm3)
 
-    def forward_sa(self, tgt, query_pos, attn_mask):
+    def forward_sa(self, tgt, query_pos, attn_mask, batch_first=False):
         q = k = tgt if query_pos is None else tgt + query_pos
         if FUSED_SELF_ATTN and tgt.is_cuda and _plain_mha(self.self_attn):
-            tgt2 = _self_attention(self.self_attn, q, tgt, attn_mask)
+            tgt2 = _self_attention(self.self_attn, q, tgt, attn_mask, batch_first)
+        elif batch_first:
+            tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1), attn_mask=attn_mask,
+                                  need_weights=False)[0].transpose(0, 1)
         else:
             tgt2 = self.self_attn(q, k, tgt, attn_mask=attn_mask, need_weights=False)[0]
         return _add_norm(tgt, tgt2, self.dropout2, self.norm2)
 
     def forward_ca(self, tgt, query_pos, reference_points, memory, spatial_shapes,
-                   level_start_index, key_padding_mask, value=None, grad_slot=None):
+                   level_start_index, key_padding_mask, value=None, grad_slot=None, batch_first=False):
         q = tgt if query_pos is None else tgt + query_pos
         kw = {} if value is None else {"value": value, "grad_slot": grad_slot}
-        tgt2 = self.cross_attn(q.transpose(0, 1), reference_points.transpose(0, 1).contiguous(),
-                               memory.transpose(0, 1), spatial_shapes, level_start_index,
-                               key_padding_mask, **kw).transpose(0, 1)
+        if batch_first:        # tgt, reference_points are [bs, nq, .]: the layout the attention module works in
+            tgt2 = self.cross_attn(q, reference_points, memory.transpose(0, 1), spatial_shapes, level_start_index,
+                                   key_padding_mask, **kw)
+        else:
+            tgt2 = self.cross_attn(q.transpose(0, 1), reference_points.transpose(0, 1).contiguous(),
+                                   memory.transpose(0, 1), spatial_shapes, level_start_index,
+                                   key_padding_mask, **kw).transpose(0, 1)
         return _add_norm(tgt, tgt2, self.dropout1, self.norm1)
 
     def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None,
                 tgt_key_padding_mask=None, tgt_reference_points=None, memory=None,
                 memory_key_padding_mask=None, memory_level_start_index=None,
                 memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
-                cross_attn_mask=None, memory_value=None, memory_grad_slot=None):
+                cross_attn_mask=None, memory_value=None, memory_grad_slot=None, batch_first=False):
+        """batch_first: tgt / tgt_query_pos / tgt_reference_points are [bs, nq, .] instead of the reference's
+        [nq, bs, .] (same values; every op but the self-attention is per row)."""
         for name in self.module_seq:
             if name == "ffn":
                 tgt = self.forward_ffn(tgt)
             elif name == "ca":
                 tgt = self.forward_ca(tgt, tgt_query_pos, tgt_reference_points, memory,
                                       memory_spatial_shapes, memory_level_start_index,
-                                      memory_key_padding_mask, memory_value, memory_grad_slot)
+                                      memory_key_padding_mask, memory_value, memory_grad_slot, batch_first)
             else:
-                tgt = self.forward_sa(tgt, tgt_query_pos, self_attn_mask)
+                tgt = self.forward_sa(tgt, tgt_query_pos, self_attn_mask, batch_first)
         return tgt
 
 
@@ -413,6 +433,15 @@ class TransformerDecoder(nn.Module):
                           .masked_fill_(tgt_mask, float("-inf")))
                 self._additive_mask = cached
             tgt_mask = cached[1]
+        # On the device the layers run BATCH-first ([bs, nq, C]: what the caller's tensors are in memory --
+        # it hands over transposed views -- and what the cross-attention works in), so no sub-block has
+        # to re-lay its input or output; the reference's [nq, bs, C] order otherwise.  Per-row values are
+        # identical; the results are handed back batch-first either way.
+        bf = BATCH_FIRST_DECODER and tgt.is_cuda and tgt.dim() == 3 and refpoints_unsigmoid.dim() == 3
+        if bf:
+            output = output.transpose(0, 1)
+            output = output if output.is_contiguous() else output.contiguous()
+            refpoints_unsigmoid = refpoints_unsigmoid.transpose(0, 1)
         reference_points = refpoints_unsigmoid.sigmoid()
         ref_points = [reference_points]
         # The memory feeds every layer's value projection.  All six projections as ONE autograd node
@@ -430,10 +459,8 @@ class TransformerDecoder(nn.Module):
         else:
             mem_l = (memory,) * len(self.layers)
         for layer_id, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
-                ref_in = reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[None, :]
-            else:
-                ref_in = reference_points[:, :, None] * valid_ratios[None, :]
+            vr = torch.cat([valid_ratios, valid_ratios], -1) if reference_points.shape[-1] == 4 else valid_ratios
+            ref_in = reference_points[:, :, None] * (vr[:, None] if bf else vr[None, :])
             query_sine_embed = gen_sineembed_for_position(ref_in[:, :, 0, :])
             query_pos = self.ref_point_head(query_sine_embed)
             output = layer(tgt=output, tgt_query_pos=query_pos,
@@ -443,7 +470,7 @@ class TransformerDecoder(nn.Module):
                            memory_key_padding_mask=memory_key_padding_mask,
                            memory_level_start_index=level_start_index,
                            memory_spatial_shapes=spatial_shapes, memory_pos=pos,
-                           self_attn_mask=tgt_mask, cross_attn_mask=memory_mask,
+                           self_attn_mask=tgt_mask, cross_attn_mask=memory_mask, batch_first=bf,
                            **({} if batched is None else {"memory_value": batched[0][layer_id],
                                                           "memory_grad_slot": (batched[1], layer_id)}))
             if self.bbox_embed is not None:
@@ -452,6 +479,8 @@ class TransformerDecoder(nn.Module):
                 reference_points = new_ref.detach()
                 ref_points.append(reference_points if self.use_detached_boxes_dec_out else new_ref)
             intermediate.append(layer_norm(output, self.norm))
+        if bf:
+            return [intermediate, ref_points]
         return [[x.transpose(0, 1) for x in intermediate],
                 [r.transpose(0, 1) for r in ref_points]]
 

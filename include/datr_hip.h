@@ -382,6 +382,20 @@ int datr_ema_update_f32(const datr_ema_tensor *tensors, const datr_ema_piece *pi
                         double decay, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Stacked operands of ONE GEMM for two linear layers that read the same input -- MSDeformAttn's
+ * `sampling_offsets` and `attention_weights` (/root/reference/models/dino/ops/modules/ms_deform_attn.py:96-97):
+ * w [Ra + Rb, C] = [diag(scale) wa ; wb], b [Ra + Rb] = [scale * ba ; bb]; scale [Ra] may be NULL (with 2-d
+ * reference points it is 1 / W_l, 1 / H_l per offset feature: the division of :101-104 folded into the
+ * weights).  backward (scale != NULL only): d_wa = diag(scale) d_w[:Ra], d_ba = scale * d_b[:Ra]; the other
+ * gradients are row slices of d_w / d_b.  C % 4 == 0 (csrc/stack_linear.hip).
+ * ------------------------------------------------------------------------------------------ */
+int datr_stack_linear_forward_f32(const float *wa, const float *ba, const float *wb, const float *bb,
+                                  const float *scale, int64_t Ra, int64_t Rb, int64_t C, float *w, float *b,
+                                  void *stream);
+int datr_stack_linear_backward_f32(const float *d_w, const float *d_b, const float *scale, int64_t Ra, int64_t C,
+                                   float *d_wa, float *d_ba, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Iterative box refinement of the decoder, new_ref = sigmoid(delta + inverse_sigmoid(ref)) with
  * inverse_sigmoid(x) = log(clamp(x, 0, 1).clamp(min = eps) / (1 - clamp(x, 0, 1)).clamp(min = eps))
  * (/root/reference/models/dino/deformable_transformer.py:738-744, /root/reference/models/dino/dino.py:316-322,

@@ -299,6 +299,93 @@ def test_attention_d32_forward_and_backward_match_float64_math(L, masked):
     torch.testing.assert_close(g_v.double(), r_v, rtol=1e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize("batch_major", [False, True])
+def test_attention_qk_d32_equals_attention_d32_in_both_memory_orders(batch_major):
+    """The merged-projection entry (one qk tensor in, one gradient out) runs the same kernels as attention_d32:
+    bitwise the same output and gradients, for sequence-major memory and for [L, N, .] views of batch-major
+    tensors (the decoder's batch-first layout); output and gradients come in the memory order of qk."""
+    from datr_amd.fused import attention_d32, attention_qk_d32
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    L, N, H = 300, 4, 8
+    E = 32 * H
+    mask = 0.1 * torch.randn(L, L, device=dev)
+    mask[100:, :100] = float("-inf")
+    if batch_major:
+        qk = torch.randn(N, L, 2 * E, device=dev).transpose(0, 1).requires_grad_(True)
+        v = torch.randn(N, L, E, device=dev).transpose(0, 1).requires_grad_(True)
+        go = torch.randn(N, L, E, device=dev).transpose(0, 1)
+    else:
+        qk = torch.randn(L, N, 2 * E, device=dev).requires_grad_(True)
+        v = torch.randn(L, N, E, device=dev).requires_grad_(True)
+        go = torch.randn(L, N, E, device=dev)
+    out = attention_qk_d32(qk, v, mask, H)
+    g_qk, g_v = torch.autograd.grad(out, (qk, v), go)
+    assert out.stride() == v.stride() and g_qk.stride() == qk.stride() and g_v.stride() == v.stride()
+    q, k = qk.split(E, dim=-1)
+    ref = attention_d32(q, k, v, mask, H)
+    r_qk, r_v = torch.autograd.grad(ref, (qk, v), go)
+    assert torch.equal(out, ref) and torch.equal(g_qk, r_qk) and torch.equal(g_v, r_v)
+
+
+def test_decoder_layer_batch_first_equals_sequence_first():
+    """DeformableTransformerDecoderLayer with batch_first=True ([bs, nq, C] in and out) against the reference
+    order ([nq, bs, C]): the same kernels on the same rows -- outputs and parameter gradients agree to fp32
+    GEMM rounding (the library may pick another kernel for another row order)."""
+    from datr_amd.transformer import DeformableTransformerDecoderLayer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    shapes = [(20, 27), (10, 14), (5, 7), (3, 4)]
+    S = sum(h * w for h, w in shapes)
+    spatial = torch.tensor(shapes, dtype=torch.int64, device=dev)
+    lsi = torch.cat([spatial.new_zeros(1), (spatial[:, 0] * spatial[:, 1]).cumsum(0)[:-1]])
+    layer = DeformableTransformerDecoderLayer(256, 512, 0.0, "relu", 4, 8, 4).to(dev)
+    bs, nq = 3, 130
+    tgt = torch.randn(bs, nq, 256, device=dev)
+    pos = torch.randn(bs, nq, 256, device=dev)
+    ref = torch.rand(bs, nq, 4, 4, device=dev) * 0.6 + 0.2
+    ref[..., 2:] *= 0.3
+    memory = torch.randn(bs, S, 256, device=dev)
+    mask = torch.zeros(nq, nq, device=dev)
+    mask[30:, :30] = float("-inf")
+    go = torch.randn(bs, nq, 256, device=dev)
+    res = []
+    for bf in (True, False):
+        t = tgt.clone().requires_grad_(True)
+        tr = (lambda x: x) if bf else (lambda x: x.transpose(0, 1))
+        out = layer(tgt=tr(t), tgt_query_pos=tr(pos), tgt_reference_points=tr(ref).contiguous(),
+                    memory=memory.transpose(0, 1), memory_level_start_index=lsi, memory_spatial_shapes=spatial,
+                    self_attn_mask=mask, batch_first=bf)
+        out = tr(out)
+        grads = torch.autograd.grad(out, [t] + list(layer.parameters()), go)
+        res.append((out.detach(), grads))
+    (o1, g1), (o2, g2) = res
+    torch.testing.assert_close(o1, o2, rtol=1e-4, atol=1e-5)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_stack_linear_matches_torch_cat_and_scale(scaled):
+    """csrc/stack_linear.hip: [diag(s) wa ; wb], [s * ba ; bb] and the gradients of the four parameters against the
+    torch formulation (two multiplies + two concatenations) -- products of two floats, so bitwise equal."""
+    from datr_amd.msda import stack_linear
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    wa, ba = torch.randn(256, 256, device=dev, requires_grad=True), torch.randn(256, device=dev, requires_grad=True)
+    wb, bb = torch.randn(128, 256, device=dev, requires_grad=True), torch.randn(128, device=dev, requires_grad=True)
+    s_ = (torch.rand(256, device=dev) + 0.01) if scaled else None
+    gw, gb = torch.randn(384, 256, device=dev), torch.randn(384, device=dev)
+    w, b = stack_linear(wa, ba, wb, bb, s_)
+    got = torch.autograd.grad([w, b], [wa, ba, wb, bb], [gw, gb])
+    wa2, ba2 = (wa * s_[:, None], ba * s_) if scaled else (wa, ba)
+    w_ref, b_ref = torch.cat([wa2, wb], 0), torch.cat([ba2, bb], 0)
+    ref = torch.autograd.grad([w_ref, b_ref], [wa, ba, wb, bb], [gw, gb])
+    assert torch.equal(w, w_ref) and torch.equal(b, b_ref)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+
+
 @pytest.mark.parametrize("ref_dim,Lq", [(2, 701), (4, 300)])
 def test_fused_sampling_prologue_matches_torch_ops(ref_dim, Lq):
     """csrc/msda_prologue.hip (softmax + sampling locations from the merged query projection,

@@ -27,6 +27,7 @@ class Rec(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.rows = collections.Counter()
+        self.big = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
@@ -42,8 +43,25 @@ class Rec(TorchDispatchMode):
             if "datr_amd/" in fr.filename:
                 where = f"{fr.filename.split('datr_amd/')[-1]}:{fr.lineno} {fr.name}"
                 break
+        node = torch._C._current_autograd_node()
+        if node is not None and "_backward_and_step" in where:
+            # a native autograd node: anomaly mode kept the forward stack that created it
+            where = "bwd " + node.name()
+            tb = node.metadata.get("traceback_", None)
+            if tb:
+                for line in reversed(tb):
+                    if "datr_amd/" in line and "File" in line:
+                        f_ = line.split("datr_amd/")[-1].split('"')[0]
+                        ln = line.split("line ")[1].split(",")[0]
+                        fn = line.split(" in ")[1].split("\n")[0] if " in " in line else ""
+                        where = f"bwd {node.name()} <- {f_}:{ln} {fn}"
+                        break
         big = max([a.numel() for a in args if torch.is_tensor(a)] + [o.numel() for o in outs if torch.is_tensor(o)] + [0])
         self.rows[(where, name, "big" if big >= 1 << 20 else "small")] += 1
+        if big >= 1 << 20:
+            shp = next((tuple(o.shape) for o in outs if torch.is_tensor(o) and o.numel() == big), None) or \
+                next(tuple(a.shape) for a in args if torch.is_tensor(a) and a.numel() == big)
+            self.big[(where, name, shp)] += 1
         return out
 
 
@@ -58,7 +76,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 torch.autograd.set_multithreading_enabled(False)
 rec = Rec()
-with rec:
+with torch.autograd.detect_anomaly(check_nan=False), rec:
     tr.step(samples, targets)
 torch.cuda.synchronize()
 total = sum(rec.rows.values())
@@ -69,4 +87,7 @@ for (w, n, s), c in rec.rows.items():
 print("---- by source line")
 for w, c in by_where.most_common(a.rows):
     ops = collections.Counter({n + ("*" if s == "big" else ""): c2 for (w2, n, s), c2 in rec.rows.items() if w2 == w})
-    print(f"{c:5d}  {w:60s} " + " ".join(f"{n}x{k}" for n, k in ops.most_common(6)))
+    print(f"{c:5d}  {w:84s} " + " ".join(f"{n}x{k}" for n, k in ops.most_common(6)))
+print("---- ops on >= 1M elements: source, op, shape")
+for (w, n, shp), c in sorted(rec.big.items(), key=lambda kv: -kv[1] * __import__("math").prod(kv[0][2])):
+    print(f"{c:4d}  {n:24s} {str(shp):28s} {w}")
