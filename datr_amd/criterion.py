@@ -216,7 +216,32 @@ class SetCriterion(nn.Module):
         return {k + suffix: z() for k in ("loss_bbox_dn", "loss_giou_dn", "loss_ce_dn", "loss_xy_dn",
                                           "loss_hw_dn", "cardinality_error_dn")}
 
-    def _family_losses(self, outs, targets, indices_per_out, num_boxes, log_first):
+    def _dn_columns(self, targets, single_pad, groups, G, device):
+        """(set, image, query, target) index columns of the de-noising family: they depend on the ground-truth
+        counts and the de-noising layout only, so they are built once per (counts, layout) -- the generic
+        path issued ~60 small launches per step for them (arange / repeat / full / add / cat)."""
+        counts = tuple(len(t["labels"]) for t in targets)
+
+        def make():
+            pos, _ = self._dn_indices(targets, single_pad, groups, device)
+            gi, bi, qi, ti, off = [], [], [], [], 0
+            for g in range(G):
+                off = 0
+                for b, (src, tgt) in enumerate(pos):
+                    n = src.numel()
+                    if n:
+                        gi.append(torch.full((n,), g, dtype=torch.int64, device=device))
+                        bi.append(torch.full((n,), b, dtype=torch.int64, device=device))
+                        qi.append(src)
+                        ti.append(tgt + off)
+                    off += counts[b]
+            if not gi:
+                z = torch.zeros(0, dtype=torch.int64, device=device)
+                return z, z, z, z
+            return torch.cat(gi), torch.cat(bi), torch.cat(qi), torch.cat(ti)
+        return _cached(("dn_cols", G, counts, single_pad, groups, str(device)), make)
+
+    def _family_losses(self, outs, targets, indices_per_out, num_boxes, log_first, columns=None):
         """All requested losses for a FAMILY of prediction sets with identical shapes (e.g. the
         final + auxiliary + two-stage outputs, or the de-noising outputs of every layer) in one
         batched evaluation.  Same arithmetic per element as get_loss() on each set; the focal
@@ -235,7 +260,9 @@ class SetCriterion(nn.Module):
         labels_cat = torch.cat([t["labels"] for t in targets])
         boxes_cat = torch.cat([t["boxes"] for t in targets])
         packed = getattr(indices_per_out, "packed", None)
-        if packed is not None:
+        if columns is not None:
+            g_idx, b_idx, q_idx, t_idx = columns
+        elif packed is not None:
             # indices straight from the device solver, already in (set, image, query) order: the
             # set / image / box-offset columns are static per (G, counts) and cached
             g_idx, b_idx, off_idx = _static_index_columns(G, tuple(counts), device)
@@ -394,11 +421,11 @@ class SetCriterion(nn.Module):
                 known = dn_meta["output_known_lbs_bboxes"]
                 groups, pad_size = dn_meta["num_dn_group"], dn_meta["pad_size"]
                 assert pad_size % groups == 0
-                dn_pos_idx, _ = self._dn_indices(targets, pad_size // groups, groups, device)
                 dn_sets = [{"pred_logits": known["pred_logits"], "pred_boxes": known["pred_boxes"]}]
                 dn_sets += list(known.get("aux_outputs", []))
-                dn_l = self._family_losses(dn_sets, targets, [dn_pos_idx] * len(dn_sets),
-                                           num_boxes * groups, log_first=False)
+                cols = self._dn_columns(targets, pad_size // groups, groups, len(dn_sets), device)
+                dn_l = self._family_losses(dn_sets, targets, [None] * len(dn_sets),
+                                           num_boxes * groups, log_first=False, columns=cols)
                 losses.update({k + "_dn": v for k, v in dn_l[0].items()})
             else:
                 losses.update(self._zero_dn(device))

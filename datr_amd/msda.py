@@ -515,7 +515,7 @@ class OffsetMonitor:
     LAG = 2                 # calls between a measurement and its use
     MARGIN_PX = 0.25
     CLIP_PX = 8.0
-    GRID_PX = 0.25          # envelopes are rounded outward to this grid ...
+    GRID_PX = float(__import__("os").environ.get("DATR_MSDA_ENVELOPE_GRID", "0.0625"))   # envelopes are rounded outward to this grid (0.25 px cost a window pixel: +0.28 ms per step) ...
     SHRINK_PX = 0.75        # ... and only replaced when they grow, or shrink by at least this much somewhere
 
     def __init__(self, every: int = 50):
@@ -538,7 +538,7 @@ class OffsetMonitor:
             if host.numel() == 1 + 128:
                 import numpy as np
                 env = host[1:].numpy().reshape(8, 4, 4).copy()
-                # Outward to the 0.25-px grid, and KEEP the current envelope while the new one fits inside it
+                # Outward to the GRID_PX grid, and KEEP the current envelope while the new one fits inside it
                 # and is not much tighter: the measurement is a quantile of a random sub-sample, and an
                 # envelope that differs in the last digit is a new plan for the library (a grid search on the
                 # host, possibly another kernel variant's first launch: measured 130 ms for the step that
