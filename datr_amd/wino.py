@@ -17,11 +17,9 @@ from torch.autograd.function import once_differentiable
 # 0 = the backbone's 3x3 convolutions stay on the library (A/B measurements)
 OWN_BACKBONE_3X3 = os.environ.get("DATR_OWN_CONV3X3", "1") != "0"
 # Widest layer routed through the own kernel: every stride-1 bottleneck of ResNet-50 (64 .. 512 channels).
-# Measured at 4 x 1333x800 (tools/bench_wino.py, conv + frozen BN + ReLU, own vs library + fused affine
-# pass): 64 ch 179 vs 216 us, 128 ch 178 vs 191 us (fwd + bwd 510 vs 545); 256 ch 197 vs 184 us, 512 ch
-# 194 vs 176 us -- the 50x84 / 25x42 maps fill only 1.5 / 0.75 rounds of 16x16-pixel workgroups, so at
-# layer3 / layer4 the own kernel is level with the library, not ahead (the step does not move either way);
-# they are routed here so that the path runs without the convolution library.
+# Per launch at 4 x 1333x800 (profiles/r04_wino_s32.txt, conv + frozen BN + ReLU in one launch): 64 ch 139 us,
+# 128 ch 132 us, 256 ch 144 us, 512 ch 167 us; the library's convolution alone (without its affine + ReLU pass)
+# ran 216 / 191 / 184 / 176 us on these layers (profiles/r02_wino.md).
 OWN_BACKBONE_3X3_MAX_CH = int(os.environ.get("DATR_OWN_CONV3X3_MAX_CH", "512"))
 
 
@@ -142,8 +140,8 @@ class _Conv3x3BnRelu(torch.autograd.Function):
 
 class _Conv3x3OwnWgrad(torch.autograd.Function):
     """conv2d(x, w, stride 1, padding 1) with the library's forward and data gradient and the
-    Winograd-domain weight gradient (csrc/wino_wgrad.hip): the wide bottlenecks (layer3 / layer4),
-    whose small maps the library's forward kernels fill better than wino.hip's 16x16-pixel workgroups."""
+    Winograd-domain weight gradient (csrc/wino_wgrad.hip): bottlenecks
+    wider than DATR_OWN_CONV3X3_MAX_CH (none in ResNet-50 at the default of 512: a fallback)."""
 
     @staticmethod
     def forward(ctx, x, w):
