@@ -15,6 +15,7 @@
 // forward 3 KiB instead of 5, backward 4 KiB instead of 5.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 #include "datr_hip.h"
@@ -62,6 +63,45 @@ __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(
         o.z = dz * rs * g.z + b.z; o.w = dw * rs * g.w + b.w;
         y[r * 64 + lane] = o;
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+}
+
+// score[r] = max_c ( LayerNorm(x[r]) . W[c] + b[c] ): the two-stage query selection's class score of every
+// encoder token (/root/reference/models/dino/deformable_transformer.py:335-342: enc_output_norm, the class
+// head, `.max(-1)[0]` feeding top-k) without writing the normalised rows or the [rows, C] logits -- in
+// training nothing else reads them (the selected rows are re-projected with autograd).  One wave per row as
+// above; the class weights sit in registers (nc <= kMaxClasses float4 per lane).
+constexpr int kMaxClasses = 16;
+__global__ __launch_bounds__(kThreads) void ln_class_max_kernel(
+    const float4 *__restrict__ x, const float4 *__restrict__ gamma, const float4 *__restrict__ beta,
+    const float4 *__restrict__ W, const float *__restrict__ bias, int nc, int64_t rows, float eps,
+    float *__restrict__ score)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 g = gamma[lane], b = beta[lane];
+    float4 w[kMaxClasses];
+    float bc[kMaxClasses];
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) {
+        w[c] = c < nc ? W[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bc[c] = c < nc ? bias[c] : 0.f;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * kWaves + wave; r < rows; r += (int64_t)gridDim.x * kWaves) {
+        const float4 s = x[r * 64 + lane];
+        const float mu = wave_sum(s.x + s.y + s.z + s.w) * (1.f / kC);
+        const float dx = s.x - mu, dy = s.y - mu, dz = s.z - mu, dw = s.w - mu;
+        const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / kC);
+        const float rs = rsqrtf(var + eps);
+        const float ox = dx * rs * g.x + b.x, oy = dy * rs * g.y + b.y, oz = dz * rs * g.z + b.z, ow = dw * rs * g.w + b.w;
+        float best = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c) {
+            if (c < nc) {                          // wave-uniform
+                const float p = wave_sum(ox * w[c].x + oy * w[c].y + oz * w[c].z + ow * w[c].w) + bc[c];
+                best = fmaxf(best, p);
+            }
+        }
+        if (lane == 0) score[r] = best;
     }
 }
 
@@ -162,6 +202,19 @@ extern "C" int datr_add_layernorm_forward_f32(const float *x, const float *res, 
                        reinterpret_cast<const float4 *>(res), reinterpret_cast<const float4 *>(gamma),
                        reinterpret_cast<const float4 *>(beta), rows, eps, reinterpret_cast<float4 *>(y),
                        mean, rstd);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+extern "C" int datr_layernorm_class_max_f32(const float *x, const float *gamma, const float *beta, const float *w,
+                                            const float *bias, int64_t rows, int64_t C, int64_t classes, float eps,
+                                            float *score, void *stream) {
+    if (rows < 0 || C != kC || classes < 1 || classes > kMaxClasses) return rows < 0 ? DATR_EINVAL : DATR_EUNSUPPORTED;
+    if (rows == 0) return DATR_OK;
+    if (!x || !gamma || !beta || !w || !bias || !score) return DATR_EINVAL;
+    hipLaunchKernelGGL(ln_class_max_kernel, dim3((unsigned)grid_for(rows)), dim3(kThreads), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(gamma),
+                       reinterpret_cast<const float4 *>(beta), reinterpret_cast<const float4 *>(w), bias, (int)classes,
+                       rows, eps, score);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .fused import FastLinear
-from .fused import attention_qk_d32, fan_out, layer_norm, linear_relu, refine_boxes
+from .fused import attention_qk_d32, fan_out, layer_norm, layer_norm_class_max, linear_relu, refine_boxes
 from .fused import linear as fused_linear
 from .msda import MSDeformAttn, value_projections
 from .nested import inverse_sigmoid
@@ -487,6 +487,7 @@ class TransformerDecoder(nn.Module):
 
 # DATR_SELECTED_ROWS_BWD=0: differentiate enc_output over all encoder tokens, as the reference does
 SELECTED_ROWS_BACKWARD = __import__("os").environ.get("DATR_SELECTED_ROWS_BWD", "1") != "0"
+FUSED_CLASS_SCORES = __import__("os").environ.get("DATR_FUSED_CLASS_SCORES", "1") != "0"   # A/B switch
 _POS_TABLES = {}          # ids of the per-level position embeddings -> (weak refs, flattened [N, S, C] table)
 
 
@@ -738,9 +739,15 @@ class DeformableTransformer(nn.Module):
             with torch.set_grad_enabled(torch.is_grad_enabled() and not sparse):
                 output_memory, output_proposals = gen_encoder_output_proposals(
                     memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding)
-                output_memory = layer_norm(self.enc_output(output_memory), self.enc_output_norm)
-                enc_class = self.enc_out_class_embed(output_memory)
-                topk_idx = self.select_queries(enc_class.max(-1)[0])
+                projected = self.enc_output(output_memory)
+                # training on the device: nothing but the top-k reads the normalised tokens / their logits, so
+                # they are one pass that writes neither (fused.layer_norm_class_max)
+                scores = layer_norm_class_max(projected, self.enc_output_norm, self.enc_out_class_embed) \
+                    if (sparse and FUSED_CLASS_SCORES) else None
+                if scores is None:
+                    output_memory = layer_norm(projected, self.enc_output_norm)
+                    scores = self.enc_out_class_embed(output_memory).max(-1)[0]
+                topk_idx = self.select_queries(scores)
             selected_proposals = torch.gather(output_proposals, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
             if sparse:
                 rows = torch.gather(memory, 1, topk_idx.unsqueeze(-1).repeat(1, 1, self.d_model))

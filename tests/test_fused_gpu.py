@@ -365,6 +365,28 @@ def test_decoder_layer_batch_first_equals_sequence_first():
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * max(1.0, float(b.abs().max())))
 
 
+@pytest.mark.parametrize("rows,classes", [(1, 9), (4099, 9), (777, 16), (300, 1)])
+def test_layer_norm_class_max_matches_float64(rows, classes):
+    """csrc/layernorm.hip::ln_class_max_kernel: max_c(head(norm(x))) per row against float64."""
+    from datr_amd.fused import layer_norm_class_max
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows)
+    x = torch.randn(rows, 256, device=dev) * 3 + 0.5
+    norm = torch.nn.LayerNorm(256).to(dev)
+    head = torch.nn.Linear(256, classes).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.normal_()
+        head.bias.normal_()
+    got = layer_norm_class_max(x.view(1, rows, 256), norm, head)
+    assert got.shape == (1, rows)
+    ref = torch.nn.functional.linear(
+        torch.nn.functional.layer_norm(x.double(), (256,), norm.weight.double(), norm.bias.double(), norm.eps),
+        head.weight.double(), head.bias.double()).max(-1)[0]
+    torch.testing.assert_close(got.view(-1).double(), ref, rtol=1e-5, atol=2e-6)
+    assert layer_norm_class_max(x, norm, torch.nn.Linear(256, 17).to(dev)) is None      # too many classes: caller's path
+
+
 @pytest.mark.parametrize("scaled", [False, True])
 def test_stack_linear_matches_torch_cat_and_scale(scaled):
     """csrc/stack_linear.hip: [diag(s) wa ; wb], [s * ba ; bb] and the gradients of the four parameters against the

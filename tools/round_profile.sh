@@ -15,3 +15,6 @@ python tools/probes/elementwise_audit.py $f 4 > $OUT/elementwise_audit.txt 2>&1
 s=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); head -41 $s > $OUT/rocprof_kernel_stats_top40.csv
 bash tools/pmc_step_mfma.sh $OUT/step_mfma.txt > /dev/null 2>&1; tail -3 $OUT/step_mfma.txt
 bash tools/pmc_msda_raw.sh $OUT/msda_pmc.json 2>&1 | tail -3
+python tools/probes/gemm_calls.py 2>/dev/null | grep -v "^\[gpurun\]" > $OUT/library_gemm_calls.txt; head -3 $OUT/library_gemm_calls.txt
+python tools/probes/aten_dispatch_sources.py --rows 200 2>/dev/null > $OUT/aten_dispatch.txt; grep "device ATen ops" $OUT/aten_dispatch.txt
+python tools/probes/wino_layers.py 2>/dev/null > $OUT/wino_layers.txt; tail -2 $OUT/wino_layers.txt
