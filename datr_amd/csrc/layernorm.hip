@@ -75,7 +75,7 @@ constexpr int kMaxClasses = 16;
 __global__ __launch_bounds__(kThreads) void ln_class_max_kernel(
     const float4 *__restrict__ x, const float4 *__restrict__ gamma, const float4 *__restrict__ beta,
     const float4 *__restrict__ W, const float *__restrict__ bias, int nc, int64_t rows, float eps,
-    float *__restrict__ score)
+    const unsigned char *__restrict__ row_mask, const float4 *__restrict__ row_fill, float *__restrict__ score)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 g = gamma[lane], b = beta[lane];
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kThreads) void ln_class_max_kernel(
         bc[c] = c < nc ? bias[c] : 0.f;
     }
     for (int64_t r = (int64_t)blockIdx.x * kWaves + wave; r < rows; r += (int64_t)gridDim.x * kWaves) {
-        const float4 s = x[r * 64 + lane];
+        // a masked row stands for x = row_fill (the projection of a zeroed token is its bias)
+        const float4 s = (row_mask && row_mask[r]) ? row_fill[lane] : x[r * 64 + lane];
         const float mu = wave_sum(s.x + s.y + s.z + s.w) * (1.f / kC);
         const float dx = s.x - mu, dy = s.y - mu, dz = s.z - mu, dw = s.w - mu;
         const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / kC);
@@ -207,14 +208,15 @@ extern "C" int datr_add_layernorm_forward_f32(const float *x, const float *res, 
 
 extern "C" int datr_layernorm_class_max_f32(const float *x, const float *gamma, const float *beta, const float *w,
                                             const float *bias, int64_t rows, int64_t C, int64_t classes, float eps,
-                                            float *score, void *stream) {
+                                            const uint8_t *row_mask, const float *row_fill, float *score,
+                                            void *stream) {
     if (rows < 0 || C != kC || classes < 1 || classes > kMaxClasses) return rows < 0 ? DATR_EINVAL : DATR_EUNSUPPORTED;
     if (rows == 0) return DATR_OK;
-    if (!x || !gamma || !beta || !w || !bias || !score) return DATR_EINVAL;
+    if (!x || !gamma || !beta || !w || !bias || !score || (row_mask && !row_fill)) return DATR_EINVAL;
     hipLaunchKernelGGL(ln_class_max_kernel, dim3((unsigned)grid_for(rows)), dim3(kThreads), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(gamma),
                        reinterpret_cast<const float4 *>(beta), reinterpret_cast<const float4 *>(w), bias, (int)classes,
-                       rows, eps, score);
+                       rows, eps, row_mask, reinterpret_cast<const float4 *>(row_fill), score);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 

@@ -406,10 +406,12 @@ def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
     return norm(x)
 
 
-def layer_norm_class_max(x: torch.Tensor, norm: torch.nn.LayerNorm, head: torch.nn.Linear) -> torch.Tensor:
+def layer_norm_class_max(x: torch.Tensor, norm: torch.nn.LayerNorm, head: torch.nn.Linear, row_mask=None,
+                         row_fill=None) -> torch.Tensor:
     """head(norm(x)).max(-1)[0] for x [..., 256] -- the score the two-stage selection ranks encoder tokens by
     (/root/reference/models/dino/deformable_transformer.py:335-342) -- in one pass (csrc/layernorm.hip:
-    neither the normalised rows nor the logits are written).  No gradient: callers use it where the reference's
+    neither the normalised rows nor the logits are written).  row_mask (bool, one entry per row) / row_fill [256]:
+    masked rows are evaluated as if x[r] were row_fill.  No gradient: callers use it where the reference's
     values feed top-k only.  None when the kernel does not apply."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and norm.elementwise_affine
             and norm.bias is not None and tuple(norm.normalized_shape) == (256,) and isinstance(head, torch.nn.Linear)
@@ -419,10 +421,16 @@ def layer_norm_class_max(x: torch.Tensor, norm: torch.nn.LayerNorm, head: torch.
     x2 = x.reshape(-1, 256)
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
     out = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+    mask = fill = None
+    if row_mask is not None:
+        mask = row_mask.reshape(-1).contiguous()
+        fill = row_fill.detach().contiguous()
+        assert mask.dtype == torch.bool and mask.numel() == x2.shape[0] and fill.shape == (256,) and fill.dtype == torch.float32
     with torch.no_grad(), torch.cuda.device(x.device):
         rc = _native.lib.datr_layernorm_class_max_f32(
             x2.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), head.weight.contiguous().data_ptr(),
-            head.bias.data_ptr(), x2.shape[0], 256, head.out_features, float(norm.eps), out.data_ptr(),
+            head.bias.data_ptr(), x2.shape[0], 256, head.out_features, float(norm.eps),
+            0 if mask is None else mask.data_ptr(), 0 if fill is None else fill.data_ptr(), out.data_ptr(),
             _native.current_stream_ptr(x.device))
     _native.check(rc, "layernorm_class_max")
     return out.view(x.shape[:-1])

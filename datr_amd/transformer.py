@@ -188,12 +188,13 @@ _PROPOSALS = {}
 
 
 def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor,
-                                 spatial_shapes, learnedwh=None, no_padding: bool = False):
+                                 spatial_shapes, learnedwh=None, no_padding: bool = False, fill_memory: bool = True):
     """One anchor per encoder token: centre = pixel centre / valid extent, size 0.05 * 2^level;
     anchors outside (0.01, 0.99) or on padding become +inf in logit space and their memory is
     zeroed.  `spatial_shapes` is a list of (H, W) python ints or an int64 tensor.
     `no_padding=True` (the caller knows the mask is all False, without looking at it): anchors
-    and validity depend on the shapes only and are cached -- 75 small launches per call."""
+    and validity depend on the shapes only and are cached -- 75 small launches per call.
+    `fill_memory=False`: returns (invalid [N, S, 1] bool, proposals) and leaves the zeroing to the caller."""
     N = memory.shape[0]
     shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist()
               if isinstance(spatial_shapes, Tensor) else spatial_shapes)]
@@ -231,6 +232,8 @@ def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor,
             _PROPOSALS[key] = (output_proposals, invalid)
     else:
         output_proposals, invalid = cached
+    if not fill_memory:
+        return invalid, output_proposals
     output_memory = memory.masked_fill(invalid, 0.0)
     return output_memory, output_proposals
 
@@ -737,16 +740,23 @@ class DeformableTransformer(nn.Module):
             sparse = (memory.is_cuda and torch.is_grad_enabled() and memory.requires_grad and input_hw is None
                       and SELECTED_ROWS_BACKWARD)
             with torch.set_grad_enabled(torch.is_grad_enabled() and not sparse):
-                output_memory, output_proposals = gen_encoder_output_proposals(
-                    memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding)
-                projected = self.enc_output(output_memory)
-                # training on the device: nothing but the top-k reads the normalised tokens / their logits, so
-                # they are one pass that writes neither (fused.layer_norm_class_max)
-                scores = layer_norm_class_max(projected, self.enc_output_norm, self.enc_out_class_embed) \
-                    if (sparse and FUSED_CLASS_SCORES) else None
+                scores = None
+                head, proj = self.enc_out_class_embed, self.enc_output
+                if sparse and FUSED_CLASS_SCORES and isinstance(proj, nn.Linear) and proj.bias is not None:
+                    # training on the device: nothing but the top-k reads the zeroed / projected / normalised
+                    # tokens and their logits, so they are never written: the projection runs on `memory` as it
+                    # is (the projection of a zeroed token is the bias: the kernel substitutes it row-wise) and
+                    # LayerNorm + class head + max are one pass (fused.layer_norm_class_max)
+                    invalid, output_proposals = gen_encoder_output_proposals(
+                        memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding, fill_memory=False)
+                    scores = layer_norm_class_max(proj(memory), self.enc_output_norm, head,
+                                                  row_mask=invalid, row_fill=proj.bias)
+                    output_memory = memory                 # (device / dtype of what follows)
                 if scores is None:
-                    output_memory = layer_norm(projected, self.enc_output_norm)
-                    scores = self.enc_out_class_embed(output_memory).max(-1)[0]
+                    output_memory, output_proposals = gen_encoder_output_proposals(
+                        memory, mask_flatten, shapes_list, input_hw, no_padding=self.no_padding)
+                    output_memory = layer_norm(proj(output_memory), self.enc_output_norm)
+                    scores = head(output_memory).max(-1)[0]
                 topk_idx = self.select_queries(scores)
             selected_proposals = torch.gather(output_proposals, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
             if sparse:

@@ -671,10 +671,12 @@ int datr_add_layernorm_backward_f32(const float *dy, const float *x, const float
 /* score[r] = max_c (LayerNorm(x[r]) . w[c] + bias[c]): the class score the two-stage query selection ranks the
  * encoder tokens by (/root/reference/models/dino/deformable_transformer.py:335-342: enc_output_norm, the class head,
  * `.max(-1)[0]` into top-k), in one pass that writes neither the normalised rows nor the logits.  x [rows, 256]
- * contiguous, w [classes, 256], classes <= 16. */
+ * contiguous, w [classes, 256], classes <= 16.  row_mask (may be NULL): rows with a non-zero byte are evaluated
+ * with x[r] = row_fill [256] -- the reference zeroes invalid tokens BEFORE the projection that produces x
+ * (:329-333), and the projection of a zero row is its bias. */
 int datr_layernorm_class_max_f32(const float *x, const float *gamma, const float *beta, const float *w,
                                  const float *bias, int64_t rows, int64_t C, int64_t classes, float eps,
-                                 float *score, void *stream);
+                                 const uint8_t *row_mask, const float *row_fill, float *score, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Input pipeline tail on the device: ToTensor + Normalize + pad into the batch + padding mask

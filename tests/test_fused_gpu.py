@@ -385,6 +385,12 @@ def test_layer_norm_class_max_matches_float64(rows, classes):
         head.weight.double(), head.bias.double()).max(-1)[0]
     torch.testing.assert_close(got.view(-1).double(), ref, rtol=1e-5, atol=2e-6)
     assert layer_norm_class_max(x, norm, torch.nn.Linear(256, 17).to(dev)) is None      # too many classes: caller's path
+    # masked rows are evaluated on the fill vector
+    mask = torch.rand(rows, device=dev) < 0.3
+    fill = torch.randn(256, device=dev)
+    got_m = layer_norm_class_max(x, norm, head, row_mask=mask, row_fill=fill)
+    xm = torch.where(mask[:, None], fill[None, :], x)
+    torch.testing.assert_close(got_m, layer_norm_class_max(xm, norm, head), rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("scaled", [False, True])
