@@ -9,7 +9,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"] or "adamw_update" in r["Kernel_Name"]]
 per = len(adam) // max(1, len(set(int(rows[i]["Start_Timestamp"]) // 50_000_000 for i in adam)))
 # one optimizer step = a burst of FusedAdam launches; take the kernels between the bursts `steps` apart
 bursts = [adam[0]]

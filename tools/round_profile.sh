@@ -11,7 +11,6 @@ cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/prof; rocprofv3 --kernel-trace --stat
 cd $GRAFT_REPO_ROOT; f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); python tools/kstats.py $f --steps 4 --marker msda_fwd_pyr2 --per-step 6 --out $OUT/step_kernels.csv --top 140 --split msda_fwd_pyr2 --split-out $OUT/msda_fwd_by_grid.csv 2>&1 | tail -4
 python tools/kstats.py $f --steps 4 --marker msda_fwd_pyr2 --per-step 6 --top 1 --split gemm_f32_kernel --split-out $OUT/gemm_by_grid.csv > /dev/null 2>&1
 python tools/kfamilies.py $OUT/step_kernels.csv > $OUT/step_families.txt 2>&1
-python tools/probes/elementwise_audit.py $f 4 > $OUT/elementwise_audit.txt 2>&1
 s=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); head -41 $s > $OUT/rocprof_kernel_stats_top40.csv
 bash tools/pmc_step_mfma.sh $OUT/step_mfma.txt > /dev/null 2>&1; tail -3 $OUT/step_mfma.txt
 bash tools/pmc_msda_raw.sh $OUT/msda_pmc.json 2>&1 | tail -3
