@@ -24,8 +24,11 @@
 // patch of chunk c + 1 (staged in LDS, zero outside the image) is turned into V = B^T d B -- a thread
 // owns (tile, one transform row, two columns) --, the raw patch of chunk c + 2 is written to LDS and
 // that of chunk c + 3 is in flight in a register.  The FILTER operand goes from global memory (L2)
-// straight into the MFMA registers, a chunk ahead: wave (wp, wb) is the only reader of its positions
-// x channels, an LDS stage would share nothing.  A k-step multiplies channels (m, 2 + m) of the
+// straight into the MFMA registers: wave (wp, wb) is the only reader of its positions x channels, an
+// LDS stage would share nothing.  The transformed filter is stored so that a lane finds what it
+// multiplies in TWO consecutive chunks in one 16-byte load (U[pos][Cin/8][Cout][8], wino_weights);
+// there is one register set, refilled position by position as the odd chunk of a pair finishes with
+// them.  A k-step multiplies channels (m, 2 + m) of the
 // chunk: lane half `lhi` reads channels 2 lhi, 2 lhi + 1 of its tile with one ds_read_b64 (64 lanes x
 // 8 B = 512 dense bytes: conflict free).  The inverse transform A^T M A is lane-local up to one
 // exchange of 32 floats per lane between the two position halves (through LDS, once per workgroup),
@@ -33,9 +36,10 @@
 // levels of the pyramid share the filter, so they are ONE launch (level table in the arguments).
 //
 // Measured (profiles/r04_wino_s32.txt; 4 images 1333 x 800, us per launch, old -> new): 64 ch @
-// 200 x 334: 152 -> 139; 128 ch @ 100 x 167: 152 -> 132; 256 ch @ 50 x 84: 179 -> 144; 512 ch @
-// 25 x 42: 170 -> 169; 256 -> 256 @ 100 x 167 (discriminator): 441 -> 415 = 190 TF/s direct-
-// equivalent; training step -1.0 ms.  With pieces compiled out (same file): the MFMA stream with
+// 200 x 334: 152 -> 129; 128 ch @ 100 x 167: 152 -> 129; 256 ch @ 50 x 84: 179 -> 139; 512 ch @
+// 25 x 42: 170 -> 164; 256 -> 256 @ 100 x 167 (discriminator): 441 -> 392 = 201 TF/s direct-
+// equivalent; training step -1.0 ms (before the 16-byte filter loads, which took another 4-5 % off
+// every layer).  With pieces compiled out (same file): the MFMA stream with
 // prologue / epilogue alone is 72 % of the time, filter loads 10 %, transform 5 %, barrier 5 %,
 // patch copies 4 %, operand reads < 1 %.
 #include <hip/hip_runtime.h>
@@ -117,20 +121,19 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
     const int nchunks = Cin / CK;
     // The filter operand goes from global memory (L2) STRAIGHT into the MFMA registers: wave (wp, wb) is the
     // only reader of positions 8 wp .. + 7 x channels 32 wb .. + 31, so an LDS stage would share nothing.
-    // Chunk c of position pos is 64 couts x 16 B contiguous at U + ((pos * nchunks + c) * Cout) * 4 floats
-    // (U[pos][Cin/8][2][Cout][4] with (c >> 1, c & 1) = chunk of 8, half); lane half lhi takes channels
-    // 2 lhi, 2 lhi + 1: one 8-byte load per position, a chunk ahead.
+    // U[pos][Cin/8][Cout][8]: the 8 floats of (pos, 8-channel block, cout) are ordered [lhi][chunk half][m] --
+    // lane half lhi finds the channels it multiplies in BOTH 4-channel chunks of the block (2 lhi + m of each) in
+    // one 16-byte load: 8 loads per TWO chunks, issued a pair ahead.
     const __amdgpu_buffer_rsrc_t usrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(U), 0, 16 * Cin * Cout * 4, 0x00020000);
-    const unsigned b_voff = (unsigned)((co0 + wb * 32 + l31) * 16 + lhi * 8);
-    const unsigned b_pos_stride = (unsigned)nchunks * (unsigned)Cout * 16u;         // bytes between positions
-    float2 bq[2][8];
-    auto load_b = [&](int c, float2 (&dst)[8]) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const unsigned soff = (unsigned)(wp * 8 + p) * b_pos_stride + (unsigned)c * (unsigned)Cout * 16u;
-            dst[p] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(usrc, b_voff, soff, 0));
-        }
+    const unsigned b_voff = (unsigned)((co0 + wb * 32 + l31) * 32 + lhi * 16);
+    const unsigned b_pos_stride = (unsigned)(Cin / 8) * (unsigned)Cout * 32u;      // bytes between positions
+    // ONE register set: position p of the next pair is requested right after the odd chunk's last MFMA on
+    // position p (the load lands at least three MFMA slots before its first use)
+    float4 bq[8];
+    auto load_b = [&](int P, int p) {
+        const unsigned soff = (unsigned)(wp * 8 + p) * b_pos_stride + (unsigned)P * (unsigned)Cout * 32u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(usrc, b_voff, soff, 0));
     };
     // raw patch of chunk c: 180 pixels x one float4, zero outside the image (out-of-range buffer offset)
     float4 pf;
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
         const auto r0 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, poff, 0, 0);
         const auto r1 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, poff, CK * 4, 0);
         if (nchunks > 2) fetch_patch(2);
-        load_b(0, bq[0]);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) bq[p] = load_b(0, p);
         if (tid < PPIX) {
             *reinterpret_cast<float4 *>(&patch[tid * 4]) = __builtin_bit_cast(float4, r0);
             *reinterpret_cast<float4 *>(&patch[kPatchF + tid * 4]) = __builtin_bit_cast(float4, r1);
@@ -212,16 +216,16 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
     float2 a0 = *reinterpret_cast<const float2 *>(Vs + a_off);
     float2 a1 = *reinterpret_cast<const float2 *>(Vs + a_off + kVPos);
     int vi = 0;                                // c % 3
-    auto chunk = [&](int c, auto buf_tag, auto more_tag) {
-        constexpr int buf = decltype(buf_tag)::value;      // = c & 1: filter registers, raw-patch buffer
+    auto chunk = [&](int c, auto h_tag, auto more_tag) {
+        constexpr int buf = decltype(h_tag)::value;        // = c & 1: raw-patch buffer; which half of the filter pair
         constexpr bool more = decltype(more_tag)::value;
-        // invariant: V[c % 3] and bq[buf] hold chunk c; patch[buf ^ 1] holds the raw chunk c + 1; the register
-        // holds the raw chunk c + 2
+        // invariant: V[c % 3] holds chunk c, bq the filter of chunks (c & ~1, c | 1) -- positions already multiplied
+        // in the odd chunk hold the next pair's --; patch[buf ^ 1] holds the raw chunk c + 1; the register holds
+        // the raw chunk c + 2
         if (!(WINO_ABLATE & 16)) {
         if (c + 2 < nchunks) store_patch(patch + buf * kPatchF);
         if (c + 3 < nchunks) fetch_patch(c + 3);
         }
-        if (more && !(WINO_ABLATE & 1)) load_b(c + 1, bq[buf ^ 1]);
 
         const int vn = vi == 2 ? 0 : vi + 1;
         const float *va = Vs + vi * kVF + a_off;
@@ -232,18 +236,24 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
         for (int sl = 0; sl < 4; ++sl) {
             const int p0 = 2 * sl, p1 = 2 * sl + 1;
             const float *nxt = sl < 3 ? va + (2 * sl + 2) * kVPos : van;
+            const float b0x = buf ? bq[p0].z : bq[p0].x, b0y = buf ? bq[p0].w : bq[p0].y;
+            const float b1x = buf ? bq[p1].z : bq[p1].x, b1y = buf ? bq[p1].w : bq[p1].y;
             float2 an0 = a0, an1 = a1;
-            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq[buf][p0].x, acc[p0], 0, 0, 0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0x, acc[p0], 0, 0, 0);
             if (!(WINO_ABLATE & 4) && (sl < 3 || (more && WINO_BARRIER_SLOT < 3))) an0 = *reinterpret_cast<const float2 *>(nxt);
             __builtin_amdgcn_sched_barrier(0);
-            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bq[buf][p1].x, acc[p1], 0, 0, 0);
+            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1x, acc[p1], 0, 0, 0);
             if (!(WINO_ABLATE & 4) && (sl < 3 || (more && WINO_BARRIER_SLOT < 3))) an1 = *reinterpret_cast<const float2 *>(nxt + kVPos);
             __builtin_amdgcn_sched_barrier(0);
-            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq[buf][p0].y, acc[p0], 0, 0, 0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0y, acc[p0], 0, 0, 0);
             if (more && sl == WINO_TR_LOAD_SLOT && !(WINO_ABLATE & 2)) tr_load(pnext);
             if (more && sl == WINO_TR_STORE_SLOT && !(WINO_ABLATE & 2)) tr_store(vnext);
             __builtin_amdgcn_sched_barrier(0);
-            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bq[buf][p1].y, acc[p1], 0, 0, 0);
+            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1y, acc[p1], 0, 0, 0);
+            if (buf == 1 && more && !(WINO_ABLATE & 1)) {  // the next pair's filter for the two positions just finished
+                bq[p0] = load_b((c >> 1) + 1, p0);
+                bq[p1] = load_b((c >> 1) + 1, p1);
+            }
             // LDS writes only: __syncthreads() would also wait for the filter / patch loads just issued
             if (more && sl == WINO_BARRIER_SLOT && !(WINO_ABLATE & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -255,14 +265,14 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
         }
         vi = vn;
     };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
     for (int c = 0; c + 2 < nchunks; c += 2) {           // nchunks is even (Cin % 8 == 0)
-        chunk(c, B0{}, std::true_type{});
-        chunk(c + 1, B1{}, std::true_type{});
+        chunk(c, H0{}, std::true_type{});
+        chunk(c + 1, H1{}, std::true_type{});
     }
-    chunk(nchunks - 2, B0{}, std::true_type{});
-    chunk(nchunks - 1, B1{}, std::false_type{});
+    chunk(nchunks - 2, H0{}, std::true_type{});
+    chunk(nchunks - 1, H1{}, std::false_type{});
     __syncthreads();                           // everyone is done with V: the exchange buffer re-uses it
 
     // ---- inverse transform: lane = cout, register e = tile.  This wave holds transform rows
@@ -318,8 +328,9 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
     }
 }
 
-// U[pos][Cin/8][2][Cout][4] = G g G^T of every (ci, co) filter; flip = the data-gradient filter
-// (taps mirrored; the caller swaps the channel strides)
+// U[pos][Cin/8][Cout][8] = G g G^T of every (ci, co) filter, the 8 channels of a block in the order the MFMA
+// lanes consume them ([lane half][4-channel chunk of the block][k-step]: channel j = 4 h + 2 lhi + m sits at
+// 4 lhi + 2 h + m); flip = the data-gradient filter (taps mirrored; the caller swaps the channel strides)
 __global__ void wino_weights(const float *__restrict__ w, long s_co, long s_ci, long s_r, long s_s, int flip,
                              int Cin, int Cout, float *__restrict__ U)
 {
@@ -352,7 +363,8 @@ __global__ void wino_weights(const float *__restrict__ w, long s_co, long s_ci, 
             const int pos = xi * 4 + nu;
             // row 3 / column 3 of the input transform are computed negated (wino_conv_nhwc): same sign here
             const float sg = ((xi == 3) != (nu == 3)) ? -1.f : 1.f;
-            U[((((size_t)pos * nchunks + ci / CK8) * 2 + (ci % CK8) / 4) * Cout + co) * 4 + (ci & 3)] = sg * u[nu];
+            const int j = ci % CK8;
+            U[(((size_t)pos * nchunks + ci / CK8) * Cout + co) * 8 + ((j & 3) >> 1) * 4 + (j >> 2) * 2 + (j & 1)] = sg * u[nu];
         }
     }
 }

@@ -29,7 +29,7 @@ def _nhwc(x: torch.Tensor) -> torch.Tensor:
 
 def wino_filter(w: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
     """Winograd-domain filter G g G^T of a [Cout, Cin, 3, 3] weight in the layout csrc/wino.hip reads
-    ([16][Cin/8][2][Cout][4]); data_gradient=True gives the filter of the transposed convolution
+    ([16][Cin/8][Cout][8], the 8 channels of a block in MFMA-lane order); data_gradient=True gives the filter of the transposed convolution
     (channels swapped, taps mirrored)."""
     from . import _native
     co, ci = w.shape[:2]

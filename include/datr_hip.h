@@ -228,7 +228,7 @@ int datr_affine_act_backward2_f32(const float *dy, const float *dy2, const float
  * LeakyReLU backward of the PREVIOUS layer folded into this layer's data gradient.  scale / shift
  * may be NULL (1 / 0); shift = the bias for the discriminator; slope 1 = no activation;
  * out_scale = -1 folds the gradient-reversal layer into the first layer's data gradient.
- * `u` = the transformed filter from datr_wino_weights_f32: [16][Cin/8][2][Cout][4] floats.
+ * `u` = the transformed filter from datr_wino_weights_f32: [16][Cin/8][Cout][8] floats (an opaque layout: the 8 channels of a block in the order the kernel's lanes read them).
  * Cin % 8 == 0, Cout % 64 == 0.
  * datr_wino_weights_f32 reads W[co][ci][r][s] at w[co*s_co + ci*s_ci + r*s_r + s*s_s]; for the data
  * gradient pass the strides of co and ci SWAPPED (Cin, Cout = the gradient's channel counts) and
