@@ -270,6 +270,22 @@ def trained_like_step_ms(state, pool, steps, sigma=2.5):
                 m.sampling_offsets.bias.copy_(b)
 
 
+def split_bf16_step_ms(state, pool, steps):
+    """Step time with the own GEMM family's EXPERIMENTAL split-bf16 inner product switched on
+    (DATR_GEMM_SPLIT_BF16=1, read per launch; see csrc/gemm_f32.hip `Split3`): 3 warm-up + `steps` timed steps
+    after the timed region.  Reported beside the headline, never as `value`."""
+    os.environ["DATR_GEMM_SPLIT_BF16"] = "1"
+    try:
+        run_steps(state, [pool[i % len(pool)] for i in range(3)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(state, [pool[i % len(pool)] for i in range(steps)])
+        torch.cuda.synchronize()
+        return {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 2), "steps": steps, "default": False}
+    finally:
+        del os.environ["DATR_GEMM_SPLIT_BF16"]
+
+
 def teacher_student_stage(args, device):
     """BASELINE config 5 on one GPU: datr_amd.engine.train_one_epoch_with_self_training (the
     reference's epoch function, engine.py:146-342) on synthetic batches -- EMA teacher forward
@@ -357,6 +373,20 @@ def mfma_utilisation(device, rows):
            "linear1 dgrad": tflops(lambda: dh.mm(w1)), "linear1 wgrad": tflops(lambda: dh.t().mm(x)),
            "linear2 dgrad (what the own kernel replaces, without the mask / bias-sum pass)": tflops(lambda: dy.mm(w2))}
     lib_mean = 3.0 / sum(1.0 / lib[k] for k in list(lib)[:3])
+    # EXPERIMENT, off by default (DATR_GEMM_SPLIT_BF16=1; csrc/gemm_f32.hip `Split3`): the same launches with the
+    # operands split exactly into three bf16 pieces and six bf16-MFMA products accumulated in fp32 -- speed, and
+    # the error of both inner products against float64 on sampled rows, scaled by sum |a||b|
+    idx = torch.randint(0, rows, (128,), device=device)
+    ref = dy[idx].double() @ w2.double()
+    err_scale = dy[idx].double().abs() @ w2.double().abs()
+    err_fp32 = ((gemm.gemm_nn(dy, w2)[idx].double() - ref).abs() / err_scale).max().item()
+    os.environ["DATR_GEMM_SPLIT_BF16"] = "1"
+    try:
+        split = tflops(lambda: gemm.gemm_nn(dy, w2, gate=h, colsum=True))
+        split_plain = tflops(lambda: gemm.gemm_nn(dy, w2))
+        err_split = ((gemm.gemm_nn(dy, w2)[idx].double() - ref).abs() / err_scale).max().item()
+    finally:
+        del os.environ["DATR_GEMM_SPLIT_BF16"]
     out = {"bound": "mfma", "achieved": round(own, 1), "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(own / MFMA_FP32_PEAK_TFLOPS, 4),
            "kernel": f"gemm_f32_kernel (own, csrc/gemm_f32.hip): FFN hidden gradient with ReLU mask + bias-sum "
@@ -364,7 +394,15 @@ def mfma_utilisation(device, rows):
            "own_gemm_without_epilogue_tflops": round(own_plain, 1),
            "library_gemm": {"achieved": round(lib_mean, 1), "frac": round(lib_mean / MFMA_FP32_PEAK_TFLOPS, 4),
                             "kernel": f"encoder FFN GEMMs, M={rows} N=2048 K=256 (hipBLASLt / rocBLAS, fp32), measured live",
-                            "per_gemm_tflops": {k: round(v, 1) for k, v in lib.items()}}}
+                            "per_gemm_tflops": {k: round(v, 1) for k, v in lib.items()}},
+           "experimental_split_bf16": {
+               "default": False, "switch": "DATR_GEMM_SPLIT_BF16=1",
+               "what": "the own GEMM family's inner product with both fp32 operands split exactly into three bf16 pieces "
+                       "(24 mantissa bits = 3 x 8) and the six largest piece products accumulated in fp32 by "
+                       "v_mfma_f32_32x32x16_bf16; NOT used for `value`",
+               "achieved": round(split, 1), "without_epilogue_tflops": round(split_plain, 1),
+               "max_error_over_sum_abs_products_vs_float64": {"fp32_mfma": float(f"{err_fp32:.3g}"),
+                                                              "split_bf16_x6": float(f"{err_split:.3g}")}}}
     return out
 
 
@@ -640,6 +678,7 @@ def main():
                 line["roofline_trained_like"] = msda_trained_like_roofline(device, timer.shape)
                 timer.enabled = False
                 line["trained_like_offsets_ms_per_step"] = trained_like_step_ms(state, pool, args.trained_like_steps)
+                line["experimental_split_bf16_ms_per_step"] = split_bf16_step_ms(state, pool, args.trained_like_steps)
             line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
             # the whole step's matrix-pipe utilisation from the committed PMC pass (every launch of
             # five steps), beside the isolated figure above

@@ -47,6 +47,27 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// EXPERIMENTAL inner product (template parameter SP = 6, off by default: DATR_GEMM_SPLIT_BF16=1): the fp32
+// operands are split EXACTLY into three bf16 pieces each -- a = hi + mid + lo, 24 mantissa bits = 3 x 8, every
+// residual a - bf16(a) is exact in fp32 -- and the six largest of the nine piece products are accumulated in
+// fp32 by v_mfma_f32_32x32x16_bf16 (the three dropped ones are below 2^-32 of the product; measured error against
+// float64 is BELOW the fp32 MFMA chain's, tools/probes/split_bf16/).  The bf16 pipe does 16x the multiply-adds
+// per cycle of v_mfma_f32_32x32x2_f32: six products leave 2.67x the fp32 rate if the split's ~5.5 VALU
+// operations per element stay out of the way.
+struct Split3 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        s.hi[i] = h; s.mid[i] = m; s.lo[i] = (__bf16)(r1 - (float)m);
+    }
+    return s;
+}
 typedef __attribute__((address_space(3))) float lds_f;
 typedef __attribute__((address_space(3))) f4 lds_f4;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -76,7 +97,7 @@ struct GemmArgs {
 
 // AL / BL: 0 = reduction axis contiguous (KC), 1 = reduction axis strided (NC); BKT = reduction step
 // (32: 64 KB of LDS at 128 x 128, two workgroups per CU; 16: 32 KB, four per CU)
-template <int AL, int BL, int TM, int TN, int BKT>
+template <int AL, int BL, int TM, int TN, int BKT, int SP = 0>
 __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(const GemmArgs a)
 {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -238,6 +259,59 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (kt + 1 < nk) issue((kt + 1) & 1);
         const unsigned sb = (unsigned)(kt & 1) * STAGE;
+        if constexpr (SP != 0) {
+#pragma unroll
+        for (int h2 = 0; h2 < NG / 2; ++h2) {          // one bf16 k-step of 16 = two groups of 8
+            Split3 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                float x[8];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = 2 * h2 + gg;
+                    if (AL == 0) {
+                        const f4 v = *reinterpret_cast<const lds_f4 *>((uintptr_t)(sb + ard[t] + kslot[g]));
+                        x[4 * gg] = v.x; x[4 * gg + 1] = v.y; x[4 * gg + 2] = v.z; x[4 * gg + 3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            x[4 * gg + q] = *reinterpret_cast<const lds_f *>((uintptr_t)(sb + ard[t] + (unsigned)((8 * g + q) * BM * 4)));
+                    }
+                }
+                if (AL == 1 && want_asum)
+                    asum[t] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                fa[t] = split3(x);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                float x[8];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = 2 * h2 + gg;
+                    if (BL == 0) {
+                        const f4 v = *reinterpret_cast<const lds_f4 *>((uintptr_t)(sb + brd[t] + kslot[g]));
+                        x[4 * gg] = v.x; x[4 * gg + 1] = v.y; x[4 * gg + 2] = v.z; x[4 * gg + 3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            x[4 * gg + q] = *reinterpret_cast<const lds_f *>((uintptr_t)(sb + brd[t] + (unsigned)((8 * g + q) * BN * 4)));
+                    }
+                }
+                fb[t] = split3(x);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {             // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].lo, fb[j].hi, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].hi, fb[j].lo, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].mid, fb[j].mid, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].mid, fb[j].hi, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].hi, fb[j].mid, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].hi, fb[j].hi, acc[i][j], 0, 0, 0);
+                }
+        }
+        } else {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             float av[TM][4], bv[TN][4];
@@ -274,6 +348,7 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
 #pragma unroll
                 for (int i = 0; i < TM; ++i) asum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
             }
+        }
         }
     }
     if (AL == 1 && want_asum) {
@@ -440,7 +515,7 @@ __global__ __launch_bounds__(1024) void gemm_colsum_finish(const float *__restri
     }
 }
 
-struct Plan { int tm, tn, bk, ksplit; };
+struct Plan { int tm, tn, bk, ksplit, split; };
 
 // Tile and split choice, from the sweeps of tools/sweep_gemm.py / tools/probes/gemm_tn_sweep.py at the
 // step's shapes (profiles/r04_gemm_sweep.txt): SMALL tiles with many workgroups per CU win on this
@@ -450,7 +525,9 @@ struct Plan { int tm, tn, bk, ksplit; };
 // the reduction until the launch has ~2 workgroups per CU (more: the partial-sum traffic shows).
 Plan pick_plan(int form, long M, long N, long K)
 {
-    Plan p{1, 2, 16, 1};
+    Plan p{1, 2, 16, 1, 0};
+    if (const char *e = getenv("DATR_GEMM_SPLIT_BF16"))        // experimental inner product, off by default (see Split3)
+        p.split = atoi(e) != 0 ? 6 : 0;
     auto tiles = [&](const Plan &q) { return ((M + 64 * q.tm - 1) / (64 * q.tm)) * ((N + 64 * q.tn - 1) / (64 * q.tn)); };
     if (form == 2) {
         if (N <= 64) p.tn = 1;
@@ -462,6 +539,12 @@ Plan pick_plan(int form, long M, long N, long K)
     } else {
         if (N <= 64) { p.tm = 2; p.tn = 1; p.bk = 32; }        // one column tile: tall tiles, full 128-B k-rows
         else if (tiles(p) < 1024) p.tn = 1;
+    }
+    if (p.split) {
+        // the split costs VALU per FRAGMENT, the products pay per fragment PAIR: 128 x 128 tiles (two fragments
+        // of each operand per wave) where the launch still fills the chip (FFN shapes: 824 -> 730 us)
+        const Plan big{2, 2, 16, p.ksplit, p.split};
+        if (tiles(big) * (form == 2 ? p.ksplit : 1) >= 1024 && N > 64) { p.tm = 2; p.tn = 2; }
     }
     if (const char *f = getenv("DATR_GEMM_PLAN")) {            // development: "tm,tn,bk,ksplit" (ksplit 0 = keep)
         int tm = 0, tn = 0, bk = 0, ks = 0;
@@ -487,7 +570,8 @@ int launch_form(const GemmArgs &a, const Plan &p, hipStream_t st)
         return true;
     };
     bool ok;
-#define DATR_GO(TM_, TN_, BK_) ok = go(gemm_f32_kernel<AL, BL, TM_, TN_, BK_>, TM_, TN_, BK_)
+#define DATR_GO(TM_, TN_, BK_) ok = p.split ? go(gemm_f32_kernel<AL, BL, TM_, TN_, BK_, 6>, TM_, TN_, BK_) \
+                                        : go(gemm_f32_kernel<AL, BL, TM_, TN_, BK_, 0>, TM_, TN_, BK_)
     if (p.bk == 32) {
         if (p.tm == 2 && p.tn == 2) DATR_GO(2, 2, 32);
         else if (p.tm == 2) DATR_GO(2, 1, 32);
