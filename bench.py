@@ -340,7 +340,7 @@ def teacher_student_stage(args, device):
                    "pseudo_labelled_images_per_step": stats.get("num_pseudo_images")}}), flush=True)
 
 
-def mfma_utilisation(device, rows):
+def mfma_utilisation(device, rows, experiments=True):
     """Matrix-core figures, against the dense fp32 MFMA peak (exact-fp32 `v_mfma_f32_32x32x2_f32`).
     Headline = the builder's OWN largest MFMA kernel of the step, measured live with HIP events after the
     timed region: the FFN hidden gradient dz = (dy W2) * [h > 0] + bias sums, [rows, 256] x [256, 2048],
@@ -376,17 +376,19 @@ def mfma_utilisation(device, rows):
     # EXPERIMENT, off by default (DATR_GEMM_SPLIT_BF16=1; csrc/gemm_f32.hip `Split3`): the same launches with the
     # operands split exactly into three bf16 pieces and six bf16-MFMA products accumulated in fp32 -- speed, and
     # the error of both inner products against float64 on sampled rows, scaled by sum |a||b|
-    idx = torch.randint(0, rows, (128,), device=device)
-    ref = dy[idx].double() @ w2.double()
-    err_scale = dy[idx].double().abs() @ w2.double().abs()
-    err_fp32 = ((gemm.gemm_nn(dy, w2)[idx].double() - ref).abs() / err_scale).max().item()
-    os.environ["DATR_GEMM_SPLIT_BF16"] = "1"
-    try:
-        split = tflops(lambda: gemm.gemm_nn(dy, w2, gate=h, colsum=True))
-        split_plain = tflops(lambda: gemm.gemm_nn(dy, w2))
-        err_split = ((gemm.gemm_nn(dy, w2)[idx].double() - ref).abs() / err_scale).max().item()
-    finally:
-        del os.environ["DATR_GEMM_SPLIT_BF16"]
+    split = split_plain = err_fp32 = err_split = None
+    if experiments:                       # (off in the profiling runs: their per-family counters cover the product path only)
+        idx = torch.randint(0, rows, (128,), device=device)
+        ref = dy[idx].double() @ w2.double()
+        err_scale = dy[idx].double().abs() @ w2.double().abs()
+        err_fp32 = ((gemm.gemm_nn(dy, w2)[idx].double() - ref).abs() / err_scale).max().item()
+        os.environ["DATR_GEMM_SPLIT_BF16"] = "1"
+        try:
+            split = tflops(lambda: gemm.gemm_nn(dy, w2, gate=h, colsum=True))
+            split_plain = tflops(lambda: gemm.gemm_nn(dy, w2))
+            err_split = ((gemm.gemm_nn(dy, w2)[idx].double() - ref).abs() / err_scale).max().item()
+        finally:
+            del os.environ["DATR_GEMM_SPLIT_BF16"]
     out = {"bound": "mfma", "achieved": round(own, 1), "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(own / MFMA_FP32_PEAK_TFLOPS, 4),
            "kernel": f"gemm_f32_kernel (own, csrc/gemm_f32.hip): FFN hidden gradient with ReLU mask + bias-sum "
@@ -395,7 +397,7 @@ def mfma_utilisation(device, rows):
            "library_gemm": {"achieved": round(lib_mean, 1), "frac": round(lib_mean / MFMA_FP32_PEAK_TFLOPS, 4),
                             "kernel": f"encoder FFN GEMMs, M={rows} N=2048 K=256 (hipBLASLt / rocBLAS, fp32), measured live",
                             "per_gemm_tflops": {k: round(v, 1) for k, v in lib.items()}},
-           "experimental_split_bf16": {
+           "experimental_split_bf16": None if split is None else {
                "default": False, "switch": "DATR_GEMM_SPLIT_BF16=1",
                "what": "the own GEMM family's inner product with both fp32 operands split exactly into three bf16 pieces "
                        "(24 mantissa bits = 3 x 8) and the six largest piece products accumulated in fp32 by "
@@ -679,7 +681,7 @@ def main():
                 timer.enabled = False
                 line["trained_like_offsets_ms_per_step"] = trained_like_step_ms(state, pool, args.trained_like_steps)
                 line["experimental_split_bf16_ms_per_step"] = split_bf16_step_ms(state, pool, args.trained_like_steps)
-            line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1])
+            line["mfma"] = mfma_utilisation(device, timer.shape[0] * timer.shape[1], experiments=args.trained_like_steps > 0)
             # the whole step's matrix-pipe utilisation from the committed PMC pass (every launch of
             # five steps), beside the isolated figure above
             mf = os.path.join(ROOT, "profiles", STEP_MFMA_RECORD)
