@@ -1,0 +1,97 @@
+// prototypes.hip -- class-wise query prototypes of DATR's prototype alignment
+// (/root/reference/models/dino/DA_utils.py:82-120 `get_prototype_class_wise`): given the class label of every
+// decoder query (argmax of the predicted scores, computed by the caller), the mean query feature per class, which
+// classes are present, and the running count-weighted global prototypes -- the reference's one-hot matrix, its
+// [K, R] x [R, 256] product, three `where`s and the blend as ONE launch (about twenty small ATen launches per
+// call, two calls per step), and the gradient of the prototypes with respect to the features as one more.
+//   count[k]   = #{r : label[r] = k}                      present[k] = count[k] != 0
+//   proto[k]   = sum_{label[r] = k} feats[r] / max(count[k], 1)
+//   w[k]       = count[k] == 0 ? 0 : count[k] / (count[k] + amount[k])
+//   global'[k] = global[k] (1 - w[k]) + proto[k] w[k]       amount'[k] = amount[k] + count[k]
+// A workgroup = one class x 64 channels x 16 row slices; the slices meet in LDS in a fixed order (deterministic;
+// the reference's GEMM fixes no order).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "datr_hip.h"
+
+namespace {
+
+constexpr int kSlices = 16;
+
+__global__ __launch_bounds__(64 * kSlices) void prototypes_fwd(
+    const float *__restrict__ feats, const int64_t *__restrict__ labels, const float *__restrict__ global_proto,
+    const float *__restrict__ amount, int R, int C, int K, float *__restrict__ proto, float *__restrict__ present,
+    float *__restrict__ new_global, float *__restrict__ new_amount, float *__restrict__ onehot)
+{
+    __shared__ float red[kSlices][64];
+    __shared__ float cnt[kSlices];
+    const int k = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    float acc = 0.f, n = 0.f;
+    for (int r = sl; r < R; r += kSlices) {
+        const bool mine = labels[r] == k;                 // uniform over the wave
+        if (mine) { acc += feats[(size_t)r * C + c]; n += 1.f; }
+        if (blockIdx.y == 0 && (threadIdx.x & 63) == 0) onehot[(size_t)r * K + k] = mine ? 1.f : 0.f;
+    }
+    red[sl][threadIdx.x & 63] = acc;
+    if ((threadIdx.x & 63) == 0) cnt[sl] = n;
+    __syncthreads();
+    if (sl == 0) {
+        float s = 0.f, count = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSlices; ++i) { s += red[i][threadIdx.x & 63]; count += cnt[i]; }
+        const float p = s / (count == 0.f ? 1.f : count);
+        const float am = amount[k];
+        const float w = count == 0.f ? 0.f : count / (count + am);
+        proto[(size_t)k * C + c] = p;
+        new_global[(size_t)k * C + c] = global_proto[(size_t)k * C + c] * (1.f - w) + p * w;
+        if (blockIdx.y == 0 && threadIdx.x == 0) { present[k] = count != 0.f ? 1.f : 0.f; new_amount[k] = am + count; }
+    }
+}
+
+// d feats[r] = d proto[label[r]] / max(count[label[r]], 1); count = new_amount - amount is passed as `count`
+__global__ __launch_bounds__(256) void prototypes_bwd(const float4 *__restrict__ d_proto, const int64_t *__restrict__ labels,
+                                                      const float *__restrict__ count, int R, int C4, int K,
+                                                      float4 *__restrict__ d_feats)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * C4) return;
+    const int r = i / C4, c4 = i - r * C4;
+    const int k = (int)labels[r];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k >= 0 && k < K) {
+        const float n = count[k];
+        const float inv = 1.f / (n == 0.f ? 1.f : n);
+        g = d_proto[(size_t)k * C4 + c4];
+        g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+    }
+    d_feats[i] = g;
+}
+
+}  // namespace
+
+extern "C" int datr_class_prototypes_forward_f32(const float *feats, const int64_t *labels, const float *global_proto,
+                                                 const float *amount, int64_t R, int64_t C, int64_t K, float *proto,
+                                                 float *present, float *new_global, float *new_amount, float *onehot,
+                                                 void *stream) {
+    if (!feats || !labels || !global_proto || !amount || !proto || !present || !new_global || !new_amount || !onehot ||
+        R < 0 || C <= 0 || K <= 0) return DATR_EINVAL;
+    if (C % 64 != 0 || R * C > 0x7fffffffLL || R * K > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    hipLaunchKernelGGL(prototypes_fwd, dim3((unsigned)K, (unsigned)(C / 64)), dim3(64 * kSlices), 0, (hipStream_t)stream,
+                       feats, labels, global_proto, amount, (int)R, (int)C, (int)K, proto, present, new_global, new_amount,
+                       onehot);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+extern "C" int datr_class_prototypes_backward_f32(const float *d_proto, const int64_t *labels, const float *count,
+                                                  int64_t R, int64_t C, int64_t K, float *d_feats, void *stream) {
+    if (!d_proto || !labels || !count || !d_feats || R < 0 || C <= 0 || K <= 0) return DATR_EINVAL;
+    if (C % 4 != 0 || R * C > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    if (R == 0) return DATR_OK;
+    const int total = (int)(R * (C / 4));
+    hipLaunchKernelGGL(prototypes_bwd, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(d_proto), labels, count, (int)R, (int)(C / 4), (int)K,
+                       reinterpret_cast<float4 *>(d_feats));
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}

@@ -201,6 +201,50 @@ class FCDiscriminator_img(nn.Module):
                                        self.classifier.bias, *srcs))
 
 
+OWN_PROTOTYPES = __import__("os").environ.get("DATR_OWN_PROTOTYPES", "1") != "0"      # A/B switch
+
+
+class _ClassPrototypes(torch.autograd.Function):
+    """(prototypes, present, new_global, new_amount, onehot) of get_prototype_class_wise from the labels on:
+    one launch forward, one backward (only the prototypes carry a gradient, to the features)."""
+
+    @staticmethod
+    def forward(ctx, feats, labels, global_proto, amount, K):
+        from . import _native
+        R, C = feats.shape
+        dev = feats.device
+        proto = torch.empty(K, C, device=dev, dtype=torch.float32)
+        present = torch.empty(K, device=dev, dtype=torch.float32)
+        new_global = torch.empty(K, C, device=dev, dtype=torch.float32)
+        new_amount = torch.empty(K, device=dev, dtype=torch.float32)
+        onehot = torch.empty(R, K, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = _native.lib.datr_class_prototypes_forward_f32(
+                feats.data_ptr(), labels.data_ptr(), global_proto.data_ptr(), amount.data_ptr(), R, C, K,
+                proto.data_ptr(), present.data_ptr(), new_global.data_ptr(), new_amount.data_ptr(), onehot.data_ptr(),
+                _native.current_stream_ptr(dev))
+        _native.check(rc, "class_prototypes_forward")
+        ctx.save_for_backward(labels, new_amount - amount)
+        ctx.shape = (R, C, K)
+        ctx.mark_non_differentiable(present, new_global, new_amount, onehot)
+        return proto, present, new_global, new_amount, onehot
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_proto, *_):
+        from . import _native
+        labels, count = ctx.saved_tensors
+        R, C, K = ctx.shape
+        d_proto = d_proto.contiguous()
+        d_feats = torch.empty(R, C, device=d_proto.device, dtype=torch.float32)
+        with torch.cuda.device(d_proto.device):
+            rc = _native.lib.datr_class_prototypes_backward_f32(d_proto.data_ptr(), labels.data_ptr(), count.data_ptr(),
+                                                                R, C, K, d_feats.data_ptr(),
+                                                                _native.current_stream_ptr(d_proto.device))
+        _native.check(rc, "class_prototypes_backward")
+        return d_feats, None, None, None, None
+
+
 def get_prototype_class_wise(object_query_last_layer, outputs_class, num_classes,
                              global_proto=None, global_amount=None):
     """Class-wise mean of the last-layer queries, with classes assigned by argmax of the
@@ -211,6 +255,12 @@ def get_prototype_class_wise(object_query_last_layer, outputs_class, num_classes
     B, N, C = object_query_last_layer.shape
     labels = torch.argmax(outputs_class.sigmoid(), dim=2).reshape(B * N, 1)
     feats = object_query_last_layer.reshape(B * N, C)
+    if OWN_PROTOTYPES and feats.is_cuda and feats.dtype == torch.float32 and C % 64 == 0 and global_proto is not None \
+            and global_proto.dtype == torch.float32 and not global_proto.requires_grad \
+            and not torch.is_autocast_enabled():
+        # everything after the labels as one launch (csrc/prototypes.hip)
+        return _ClassPrototypes.apply(feats if feats.is_contiguous() else feats.contiguous(), labels.view(-1),
+                                      global_proto.contiguous(), global_amount.contiguous().float(), num_classes)
     onehot = torch.zeros(B * N, num_classes, device=feats.device)
     onehot.scatter_(dim=1, index=labels, value=1)
     count = onehot.sum(0)                                          # [num_classes]

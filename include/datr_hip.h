@@ -382,6 +382,22 @@ int datr_ema_update_f32(const datr_ema_tensor *tensors, const datr_ema_piece *pi
                         double decay, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Class-wise query prototypes of the prototype alignment (/root/reference/models/dino/DA_utils.py:82-120
+ * `get_prototype_class_wise`) given the class label of every query (the caller's argmax of the sigmoid scores):
+ * feats [R, C], labels [R] int64 in [0, K), global_proto [K, C], amount [K] -> proto [K, C] (class means, 0 for
+ * absent classes), present [K] in {0, 1}, new_global [K, C] = global (1 - w) + proto w with w = count / (count +
+ * amount) (0 where count = 0), new_amount [K] = amount + count, onehot [R, K].  One launch, rows summed in a fixed
+ * order.  backward: d_feats [R, C] = d_proto[label] / max(count[label], 1) (count [K] = new_amount - amount).
+ * C % 64 == 0 (csrc/prototypes.hip).
+ * ------------------------------------------------------------------------------------------ */
+int datr_class_prototypes_forward_f32(const float *feats, const int64_t *labels, const float *global_proto,
+                                      const float *amount, int64_t R, int64_t C, int64_t K, float *proto,
+                                      float *present, float *new_global, float *new_amount, float *onehot,
+                                      void *stream);
+int datr_class_prototypes_backward_f32(const float *d_proto, const int64_t *labels, const float *count, int64_t R,
+                                       int64_t C, int64_t K, float *d_feats, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Stacked operands of ONE GEMM for two linear layers that read the same input -- MSDeformAttn's
  * `sampling_offsets` and `attention_weights` (/root/reference/models/dino/ops/modules/ms_deform_attn.py:96-97):
  * w [Ra + Rb, C] = [diag(scale) wa ; wb], b [Ra + Rb] = [scale * ba ; bb]; scale [Ra] may be NULL (with 2-d

@@ -393,6 +393,39 @@ def test_layer_norm_class_max_matches_float64(rows, classes):
     torch.testing.assert_close(got_m, layer_norm_class_max(xm, norm, head), rtol=0, atol=0)
 
 
+def test_class_prototypes_kernel_matches_the_op_sequence(monkeypatch):
+    """csrc/prototypes.hip against the torch op sequence of get_prototype_class_wise (DA_utils.py:82-120): labels /
+    present / counts / one-hot exactly, class means and the running global prototypes to fp32 rounding (the
+    reference's GEMM fixes no summation order), the gradient to the features likewise; two successive calls (the
+    source and the target half of a step) with some classes absent."""
+    from datr_amd import domain
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    K = 9
+    res = []
+    for own in (True, False):
+        monkeypatch.setattr(domain, "OWN_PROTOTYPES", own)
+        torch.manual_seed(21)
+        g_proto, g_amount = torch.zeros(K, 256, device=dev), torch.zeros(K, device=dev)
+        outs = []
+        for call in range(2):
+            q = torch.randn(2, 900, 256, device=dev, requires_grad=True)
+            logits = torch.randn(2, 900, K, device=dev)
+            logits[..., 7] = -50.0                        # a class no query takes
+            if call == 0:
+                logits[..., 2] = -50.0
+            p, present, g_proto, g_amount, onehot = domain.get_prototype_class_wise(q, logits, K, g_proto, g_amount)
+            w = torch.randn(K, 256, device=dev)
+            (gq,) = torch.autograd.grad((p * w).sum(), q)
+            outs.append((p.detach(), present, g_proto, g_amount, onehot, gq))
+        res.append(outs)
+    for a, b in zip(*res):
+        assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+        for i in (0, 2, 5):
+            torch.testing.assert_close(a[i], b[i], rtol=1e-5, atol=1e-6)
+        assert not a[2].requires_grad
+
+
 @pytest.mark.parametrize("scaled", [False, True])
 def test_stack_linear_matches_torch_cat_and_scale(scaled):
     """csrc/stack_linear.hip: [diag(s) wa ; wb], [s * ba ; bb] and the gradients of the four parameters against the
