@@ -65,6 +65,7 @@ _SIGNATURES = {
     "datr_layernorm_class_max_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp],
     "datr_class_prototypes_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "datr_class_prototypes_backward_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp],
+    "datr_contrast_loss_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp],
     "datr_stack_linear_forward_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "datr_stack_linear_backward_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "datr_refine_boxes_backward_f32": [_vp, _vp, _vp, _i64, ctypes.c_float, _vp, _vp, _vp],

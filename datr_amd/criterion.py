@@ -93,6 +93,34 @@ def _static_index_columns(G, counts, device):
     return _cached(("cols", G, counts, str(device)), make)
 
 
+FUSED_CONTRAST = __import__("os").environ.get("DATR_FUSED_CONTRAST", "1") != "0"       # A/B switch
+
+
+class _ContrastLoss(torch.autograd.Function):
+    """loss_contrast_da as one launch (csrc/prototypes.hip::contrast_loss_kernel): the scalar loss and, since it is
+    a scalar, its gradients with respect to both prototype sets, which backward only scales."""
+
+    @staticmethod
+    def forward(ctx, q_s, q_t, g, m_s, m_t):
+        from . import _native
+        K, C = q_s.shape
+        loss = torch.empty(1, device=q_s.device, dtype=torch.float32)
+        dq_s, dq_t = torch.empty_like(q_s), torch.empty_like(q_t)
+        with torch.cuda.device(q_s.device):
+            rc = _native.lib.datr_contrast_loss_f32(q_s.data_ptr(), q_t.data_ptr(), g.data_ptr(), m_s.data_ptr(),
+                                                    m_t.data_ptr(), K, C, 1e-12, loss.data_ptr(), dq_s.data_ptr(),
+                                                    dq_t.data_ptr(), _native.current_stream_ptr(q_s.device))
+        _native.check(rc, "contrast_loss")
+        ctx.save_for_backward(dq_s, dq_t)
+        return loss[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        dq_s, dq_t = ctx.saved_tensors
+        return dq_s * go, dq_t * go, None, None, None
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses):
         super().__init__()
@@ -189,6 +217,10 @@ class SetCriterion(nn.Module):
         assert not g.requires_grad and not m_s.requires_grad and not m_t.requires_grad
         assert q_s.requires_grad and q_t.requires_grad
         C = q_s.shape[0]
+        if FUSED_CONTRAST and q_s.is_cuda and q_s.dtype == torch.float32 and q_s.shape == q_t.shape == g.shape \
+                and q_s.shape[1] == 256 and C <= 16 and not torch.is_autocast_enabled():
+            return _ContrastLoss.apply(q_s.contiguous(), q_t.contiguous(), g.contiguous(), m_s.contiguous().float(),
+                                       m_t.contiguous().float())
         g = F.normalize(g, dim=1).permute(1, 0).contiguous()
         logits_s = F.normalize(q_s, dim=1).mm(g)
         logits_t = F.normalize(q_t, dim=1).mm(g)

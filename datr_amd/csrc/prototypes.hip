@@ -95,3 +95,108 @@ extern "C" int datr_class_prototypes_backward_f32(const float *d_proto, const in
                        reinterpret_cast<float4 *>(d_feats));
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Contrastive prototype loss (/root/reference/models/dino/dino.py `loss_contrast_da`: cosine logits of the
+// source / target class prototypes against the global prototypes, cross entropy against eye * class_map):
+//   n_i = q_i / max(|q_i|, eps),  g^_j = g_j / max(|g_j|, eps),  z_ij = n_i . g^_j,
+//   L = (1 / K) sum_i -m_i log_softmax(z_i)_i            summed over the two domains,
+// and -- the loss being a scalar -- its gradients with respect to both prototype sets from the same launch:
+//   dL/dz_ij = m_i (softmax(z_i)_j - [i = j]) / K,  dL/dn_i = sum_j dL/dz_ij g^_j,
+//   dL/dq_i = (dL/dn_i - n_i (n_i . dL/dn_i)) / max(|q_i|, eps).
+// One workgroup (K <= 16, C = 256): ~45 small ATen launches forward + backward become one.
+namespace {
+
+constexpr int kMaxK = 16;
+
+__device__ __forceinline__ float wave_total(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void contrast_loss_kernel(const float *__restrict__ qs, const float *__restrict__ qt,
+                                                             const float *__restrict__ g, const float *__restrict__ ms,
+                                                             const float *__restrict__ mt, int K, float eps,
+                                                             float *__restrict__ loss, float *__restrict__ dqs,
+                                                             float *__restrict__ dqt)
+{
+    constexpr int C = 256;
+    __shared__ float rows[3 * kMaxK][C];           // q_s, q_t, g -> normalised in place
+    __shared__ float inv_norm[3 * kMaxK];
+    __shared__ float z[2][kMaxK][kMaxK];
+    __shared__ float dz[2][kMaxK][kMaxK];
+    __shared__ float part[2 * kMaxK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int i = tid; i < 3 * K * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        rows[r][c] = r < K ? qs[r * C + c] : r < 2 * K ? qt[(r - K) * C + c] : g[(r - 2 * K) * C + c];
+    }
+    __syncthreads();
+    for (int r = wave; r < 3 * K; r += nw) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += rows[r][c] * rows[r][c];
+        s = wave_total(s);
+        if (lane == 0) inv_norm[r] = 1.f / fmaxf(sqrtf(s), eps);
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * K * C; i += blockDim.x) rows[i / C][i % C] *= inv_norm[i / C];
+    __syncthreads();
+    for (int p = wave; p < 2 * K * K; p += nw) {               // z[d][i][j] = n_i . g^_j
+        const int d = p / (K * K), i = (p / K) % K, j = p % K;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += rows[d * K + i][c] * rows[2 * K + j][c];
+        s = wave_total(s);
+        if (lane == 0) z[d][i][j] = s;
+    }
+    __syncthreads();
+    if (tid < 2 * K) {                                         // one row of one domain per thread
+        const int d = tid / K, i = tid % K;
+        const float m = d == 0 ? ms[i] : mt[i];
+        float mx = -INFINITY;
+        for (int j = 0; j < K; ++j) mx = fmaxf(mx, z[d][i][j]);
+        float se = 0.f;
+        for (int j = 0; j < K; ++j) se += expf(z[d][i][j] - mx);
+        const float lse = mx + logf(se);
+        part[tid] = -m * (z[d][i][i] - lse) / (float)K;
+        for (int j = 0; j < K; ++j) dz[d][i][j] = m * (expf(z[d][i][j] - lse) - (i == j ? 1.f : 0.f)) / (float)K;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s0 = 0.f, s1 = 0.f;                               // ce(source) + ce(target), each a mean over its rows
+        for (int i = 0; i < K; ++i) { s0 += part[i]; s1 += part[K + i]; }
+        loss[0] = s0 + s1;
+    }
+    for (int r = wave; r < 2 * K; r += nw) {                   // gradient of row r (domain d, class i)
+        const int d = r / K, i = r % K;
+        float dn[4], dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            float s = 0.f;
+            for (int j = 0; j < K; ++j) s += dz[d][i][j] * rows[2 * K + j][c];
+            dn[u] = s;
+            dot += s * rows[r][c];
+        }
+        dot = wave_total(dot);
+        float *out = d == 0 ? dqs : dqt;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            out[i * C + c] = (dn[u] - rows[r][c] * dot) * inv_norm[r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int datr_contrast_loss_f32(const float *q_source, const float *q_target, const float *global_proto,
+                                      const float *mask_source, const float *mask_target, int64_t K, int64_t C,
+                                      float eps, float *loss, float *d_q_source, float *d_q_target, void *stream) {
+    if (!q_source || !q_target || !global_proto || !mask_source || !mask_target || !loss || !d_q_source || !d_q_target)
+        return DATR_EINVAL;
+    if (K < 1 || K > kMaxK || C != 256) return DATR_EUNSUPPORTED;
+    hipLaunchKernelGGL(contrast_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, q_source, q_target, global_proto,
+                       mask_source, mask_target, (int)K, eps, loss, d_q_source, d_q_target);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}

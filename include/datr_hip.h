@@ -397,6 +397,14 @@ int datr_class_prototypes_forward_f32(const float *feats, const int64_t *labels,
 int datr_class_prototypes_backward_f32(const float *d_proto, const int64_t *labels, const float *count, int64_t R,
                                        int64_t C, int64_t K, float *d_feats, void *stream);
 
+/* Contrastive prototype loss (/root/reference/models/dino/dino.py `loss_contrast_da`): cosine logits of the source /
+ * target class prototypes q_* [K, 256] against the global prototypes [K, 256] (F.normalize, eps), cross entropy
+ * against eye * class_map (mask_* [K] in {0, 1}), summed over the two domains -> loss [1]; and, the loss being a
+ * scalar, d loss / d q_source, d loss / d q_target [K, 256] from the same launch.  K <= 16, C == 256. */
+int datr_contrast_loss_f32(const float *q_source, const float *q_target, const float *global_proto,
+                           const float *mask_source, const float *mask_target, int64_t K, int64_t C, float eps,
+                           float *loss, float *d_q_source, float *d_q_target, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Stacked operands of ONE GEMM for two linear layers that read the same input -- MSDeformAttn's
  * `sampling_offsets` and `attention_weights` (/root/reference/models/dino/ops/modules/ms_deform_attn.py:96-97):

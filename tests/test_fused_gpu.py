@@ -393,6 +393,36 @@ def test_layer_norm_class_max_matches_float64(rows, classes):
     torch.testing.assert_close(got_m, layer_norm_class_max(xm, norm, head), rtol=0, atol=0)
 
 
+def test_fused_contrast_loss_matches_the_op_sequence(monkeypatch):
+    """csrc/prototypes.hip::contrast_loss_kernel against loss_contrast_da's torch ops (normalize, two products,
+    cross entropy against eye * class_map): value and both gradients, with absent classes (zero prototypes, mask 0)."""
+    from datr_amd import criterion as crit
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    K = 9
+    res = []
+    for fused_path in (True, False):
+        monkeypatch.setattr(crit, "FUSED_CONTRAST", fused_path)
+        torch.manual_seed(4)
+        q_s = torch.randn(K, 256, device=dev)
+        q_t = torch.randn(K, 256, device=dev) * 3
+        m_s = (torch.rand(K, device=dev) > 0.3).float()
+        m_t = (torch.rand(K, device=dev) > 0.3).float()
+        q_s[m_s == 0] = 0                                  # an absent class has a zero prototype
+        q_t[m_t == 0] = 0
+        q_s.requires_grad_(True)
+        q_t.requires_grad_(True)
+        g = torch.randn(K, 256, device=dev)
+        g[5] = 0
+        out = {"output_source": q_s, "outputs_target": q_t, "query_mask_source": m_s, "query_mask_target": m_t,
+               "global_proto": g}
+        loss = crit.SetCriterion.loss_contrast_da(None, out)
+        gs, gt = torch.autograd.grad(loss * 1.7, (q_s, q_t))
+        res.append((loss.detach(), gs, gt))
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6)
+
+
 def test_class_prototypes_kernel_matches_the_op_sequence(monkeypatch):
     """csrc/prototypes.hip against the torch op sequence of get_prototype_class_wise (DA_utils.py:82-120): labels /
     present / counts / one-hot exactly, class means and the running global prototypes to fp32 rounding (the
