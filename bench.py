@@ -272,11 +272,13 @@ def trained_like_step_ms(state, pool, steps, sigma=2.5):
 
 def split_bf16_step_ms(state, pool, steps):
     """Step time with the own GEMM family's EXPERIMENTAL split-bf16 inner product switched on
-    (DATR_GEMM_SPLIT_BF16=1, read per launch; see csrc/gemm_f32.hip `Split3`): 3 warm-up + `steps` timed steps
+    (DATR_GEMM_SPLIT_BF16=1, read per launch; see csrc/gemm_f32.hip `Split3`): 6 warm-up + `steps` timed steps
     after the timed region.  Reported beside the headline, never as `value`."""
     os.environ["DATR_GEMM_SPLIT_BF16"] = "1"
     try:
-        run_steps(state, [pool[i % len(pool)] for i in range(3)])
+        # (the trained-like measurement before this one reset the OffsetMonitors: they re-measure in the first
+        # step and switch plans in the third)
+        run_steps(state, [pool[i % len(pool)] for i in range(6)])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(state, [pool[i % len(pool)] for i in range(steps)])
