@@ -16,8 +16,9 @@
 // exact fp32).  Workgroup = 256 threads = 2 x 2 waves, tile = 8 x 16 positions x 128 output channels;
 // K runs over 16-channel chunks and, inside a chunk, over the taps.  The input PATCH of a chunk (all
 // pixels any tap of the tile touches, zero outside the image) is staged in LDS once and re-used by
-// all taps; the 16 x 128 weight slab of the next (tap, chunk) arrives by LDS-DMA while the current one
-// is multiplied.  A lane reads FOUR consecutive channels of its pixel with one ds_read_b128; with a
+// all taps; the 16 x 128 weights of the next (tap, chunk) go from L2 straight into MFMA registers while the
+// current step is multiplied (round 4; a ring of LDS slabs with a barrier per step before: forward 285-297 ->
+// 238-245 us on the three backbone layers).  A lane reads FOUR consecutive channels of its pixel with one ds_read_b128; with a
 // row stride of 20 floats the reads of a stride-1 tile are bank-conflict free; for IS = 2 the patch
 // columns are stored de-interleaved (even columns, then odd columns), so that consecutive positions
 // of one tap are consecutive LDS pixels again.  Small maps (25 x 42, 13 x 21) split K over
@@ -62,37 +63,21 @@ struct TapArgs {
     float *y;                                   // output tensor, or the partial buffer when ksplit > 1
     int Hin, Win, Cin, Cout;
     int OS, Hout, Wout;
-    int ksplit, ncls, slab0_floats;             // slabs start behind the largest class's patch
+    int ksplit, ncls;
     float slope;
     TapClass cls[4];
 };
 
-constexpr int kSlabs = 4;                      // weight-slab ring: two (tap, chunk) steps in flight
 constexpr int kPatchLoads = 9;                 // float4 per thread that cover the largest patch (17 x 33 x 4 / 256)
-
-// s_waitcnt vmcnt(n) with a run-time n (the immediate is static)
-__device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-#define DATR_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
-        DATR_W(0) DATR_W(1) DATR_W(2) DATR_W(3) DATR_W(4) DATR_W(5) DATR_W(6) DATR_W(7) DATR_W(8) DATR_W(9)
-        DATR_W(10) DATR_W(11) DATR_W(12)
-#undef DATR_W
-        default: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    }
-}
 
 template <int IS, int BNT>                      // BNT = output channels per workgroup (128)
 __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
 {
-    // Dynamic LDS (it starts at address 0: the kernel has no static LDS), addressed through plain
-    // integers: with pointers into one array the compiler assumes every slab read may alias the
-    // LDS-DMA in flight and waits for vmcnt(0) in front of each.
-    //   patch  [PH * planes * PW2][PSTR] floats at 0;  slabs [kSlabs][CK][BN] floats behind it
+    // Dynamic LDS (it starts at address 0: the kernel has no static LDS), addressed through plain integers.
+    //   patch  [PH * planes * PW2][PSTR] floats at 0
     constexpr int planes = IS;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) float lds_f;
     typedef __attribute__((address_space(3))) f4 lds_f4;
-    const unsigned slab0 = (unsigned)a.slab0_floats * 4u;                               // bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -105,7 +90,6 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
     const int ty = b % c.tiles_y; b /= c.tiles_y;
     const int n = b;
     constexpr int NJ = BNT / 64;                // 32-column accumulator tiles per wave
-    constexpr int kSlabInstr = BNT / 64;        // LDS-DMA instructions per wave and slab (1 KB each)
     const int co0 = blockIdx.y * BNT;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int Cin = a.Cin, Cout = a.Cout;
@@ -118,20 +102,21 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
-    // weight slab [CK][BNT] of (tap, chunk): 16 rows of BNT contiguous floats -> LDS by LDS-DMA
-    // (1 KB per wave instruction, no staging registers)
-    auto dma_w = [&](int w, int ci0, int buf) {
+    // The weights of a (tap, chunk) step go from global memory (L2) STRAIGHT into the MFMA registers (round 4; a ring
+    // of LDS slabs filled by LDS-DMA before): wave (wm, wn) needs the [16 ch][64 couts] block of its output-channel
+    // half -- one float per lane and k-step, 128 contiguous bytes per 32 lanes -- and only the two waves of a column
+    // half would have shared a slab, at the price of a barrier per STEP.  ONE register set, refilled k-step by k-step
+    // right after its last use with the next step's values (a full step = 32 MFMAs ahead); the barrier now guards
+    // the patch only (twice per chunk instead of once per tap).
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.wt), 0, kMaxTaps * Cin * Cout * 4, 0x00020000);    // (the host checks 9 Cin Cout 4 < 2^31)
+    const unsigned w_voff = (unsigned)((lhi * 4 * Cout + co0 + wn * (BNT / 2) + l31) * 4);
+    float bw[2][4][NJ];
+    auto load_w = [&](int w, int ci0, int grp, int q) {      // channel ci0 + 8 grp + 4 lhi + q of weight matrix w
+        const unsigned soff = (unsigned)(((size_t)w * Cin + ci0 + grp * 8 + q) * Cout * 4);
 #pragma unroll
-        for (int u = 0; u < kSlabInstr; ++u) {
-            const int e0 = (wave * kSlabInstr + u) * 256;                 // first float of this instruction's 1 KB
-            const int e = e0 + lane * 4;
-            const int row = e / BNT, col = e % BNT;
-            const float *src = a.wt + ((size_t)w * Cin + ci0 + row) * Cout + co0 + col;
-            __builtin_amdgcn_global_load_lds(
-                (__attribute__((address_space(1))) const void *)src,
-                (__attribute__((address_space(3))) void *)(uintptr_t)(slab0 + (unsigned)(buf * CK * BNT + e0) * 4u),
-                16, 0, 0);
-        }
+        for (int jn = 0; jn < NJ; ++jn)
+            bw[grp][q][jn] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, w_voff + 128u * jn, soff, 0));
     };
     // The input patch of a chunk: every thread fetches kPatchLoads float4 through a buffer descriptor
     // (pixels outside the image or past the patch get an out-of-range offset and read zeros: the
@@ -178,33 +163,23 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
     const int nchunks = Cin / CK;
     const int ch0 = (int)((long)blockIdx.z * nchunks / a.ksplit), ch1 = (int)((long)(blockIdx.z + 1) * nchunks / a.ksplit);
     const int ntaps = c.ntaps;
-    const int nsteps = (ch1 - ch0) * ntaps;
-    // step s = (chunk ch0 + s / ntaps, tap s % ntaps); its slab lives in ring slot s % kSlabs
-    auto issue_slab = [&](int s) {
-        const int cc = s / ntaps, t = s - cc * ntaps;
-        dma_w(c.widx[t], (ch0 + cc) * CK, s % kSlabs);
-    };
     fetch_patch(ch0 * CK);
-    if (nsteps > 0) issue_slab(0);
-    if (nsteps > 1) issue_slab(1);
-    wait_vm(0);
-    store_patch();
-    int s = 0;
+    if (ch0 < ch1) {
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_w(c.widx[0], ch0 * CK, grp, q);
+    }
+    store_patch();                              // (the compiler waits for the fetched registers here)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int ch = ch0; ch < ch1; ++ch) {
+        if (ch + 1 < ch1) fetch_patch((ch + 1) * CK);          // lands while this chunk's taps are multiplied
 #pragma unroll 1
-        for (int t = 0; t < ntaps; ++t, ++s) {
-            // Vector-memory operations of a thread, in issue order:
-            //   ... slab(s) | slab(s + 1) | [patch(ch + 1) at t == 0, after this step's wait] | slab(s + 2) ...
-            // slab(s) has landed once at most the operations issued after it are outstanding.
-            const bool s1 = s + 1 < nsteps, s2 = s + 2 < nsteps;
-            if (s2) issue_slab(s + 2);
-            const bool patch_in_flight = (t == 1 || t == 2) && ch + 1 < ch1 && ntaps > t;
-            wait_vm((s1 ? kSlabInstr : 0) + (s2 ? kSlabInstr : 0) + (patch_in_flight ? kPatchLoads : 0));
-            // everybody's part of slab(s) (and, at t == 0, of the patch); NOT __syncthreads(): its fence
-            // waits for vmcnt(0), i.e. for the slabs in flight
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (t == 0 && ch + 1 < ch1) fetch_patch((ch + 1) * CK);
-            const int buf = s % kSlabs;
+        for (int t = 0; t < ntaps; ++t) {
+            // the step after this one: next tap of the chunk, or the first tap of the next chunk
+            const bool last_tap = t + 1 == ntaps;
+            const bool more = !(last_tap && ch + 1 == ch1);
+            const int wn_ = c.widx[last_tap ? 0 : t + 1], cn_ = (last_tap ? ch + 1 : ch) * CK;
             const int toff = c.toff[t];
 #pragma unroll
             for (int grp = 0; grp < 2; ++grp) {          // two 8-channel groups of the chunk
@@ -214,22 +189,21 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
                     av[i] = *reinterpret_cast<const lds_f4 *>((unsigned)(abase[i] + toff + grp * 8) * 4u);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int k = grp * 8 + lhi * 4 + q;
-                    const unsigned bo = slab0 + (unsigned)((buf * CK + k) * BNT + wn * (BNT / 2) + l31) * 4u;
                     const float a0 = q == 0 ? av[0].x : q == 1 ? av[0].y : q == 2 ? av[0].z : av[0].w;
                     const float a1 = q == 0 ? av[1].x : q == 1 ? av[1].y : q == 2 ? av[1].z : av[1].w;
 #pragma unroll
                     for (int jn = 0; jn < NJ; ++jn) {
-                        const float bv = *reinterpret_cast<const lds_f *>(bo + 128u * jn);
-                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][jn], 0, 0, 0);
-                        acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][jn], 0, 0, 0);
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[grp][q][jn], acc[0][jn], 0, 0, 0);
+                        acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[grp][q][jn], acc[1][jn], 0, 0, 0);
                     }
+                    if (more) load_w(wn_, cn_, grp, q);
                 }
             }
         }
         if (ch + 1 < ch1) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the chunk's readers are done with the patch
-            store_patch();                      // (the compiler waits for the prefetched registers here)
+            store_patch();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the next chunk's patch is in place
         }
     }
 
@@ -355,14 +329,13 @@ int launch_taps(int IS, const float *x, const float *wt, const float *scale, con
     }
     if (nc == 0 || N == 0) return DATR_OK;
     a.ncls = nc;
-    a.slab0_floats = patch_floats;
     // K is split for single-class launches only (the partial buffer is laid out for one class)
     int ksplit = nc == 1 ? pick_ksplit((long)tiles * (Cout / 128), Cin / CK) : 1;
     const long per_split = (long)N * a.cls[0].Hidx * a.cls[0].Widx * Cout;
     if (ksplit > 1 && (!partial || partial_floats < per_split * ksplit)) ksplit = 1;
     a.ksplit = ksplit;
     a.y = ksplit > 1 ? partial : y;
-    const size_t lds = (size_t)(patch_floats + kSlabs * CK * 128) * sizeof(float);
+    const size_t lds = (size_t)patch_floats * sizeof(float);
     dim3 grid((unsigned)tiles, (unsigned)(Cout / 128), (unsigned)ksplit);
     auto go = [&](auto kernel) {
         static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
