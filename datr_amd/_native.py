@@ -77,6 +77,7 @@ _SIGNATURES = {
                                         _vp, _vp],
     "datr_groupnorm_nhwc_backward_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "datr_wino_weights_f32": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _vp, _vp],
+    "datr_wino_weights_pair_f32": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "datr_conv3x3_wino_nhwc_f32": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, _vp],
     "datr_add_n_f32": [_vp, _i64, _i64, _vp, _vp],

@@ -30,7 +30,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _native, gemm
-from .wino import wino_conv3x3, wino_filter, wino_wgrad
+from .wino import wino_conv3x3, wino_filter, wino_filters, wino_wgrad
 
 OWN_BOTTLENECK = os.environ.get("DATR_OWN_BOTTLENECK", "1") != "0"
 # below this many output pixels the library GEMMs are faster than the own family by more than the
@@ -80,8 +80,12 @@ class _BottleneckFn(Function):
         y1r = gemm.gemm_nt(x2, w1s, shift=shift1, relu=True)
         y1 = _like(y1r, x.shape, Cm)
         wt_t = None
+        ctx.u2_flipped = None
         if stride == 1:
-            (y2,) = wino_conv3x3([y1], wino_filter(w2), Cm, shift=shift2, scale=scale2, slope=0.0)
+            # the data gradient's filter comes out of the same launch (kept for backward: the weight does not change
+            # in between)
+            u2, ctx.u2_flipped = wino_filters(w2, want_flipped=any(ctx.needs_input_grad))
+            (y2,) = wino_conv3x3([y1], u2, Cm, shift=shift2, scale=scale2, slope=0.0)
             xs = x
         else:
             from .strided import _workspace
@@ -138,7 +142,8 @@ class _BottleneckFn(Function):
         # conv2
         dw2 = None
         if ctx.stride == 1:
-            (dz1,) = wino_conv3x3([dz2], wino_filter(w2, True), Cm, gates=[y1], gate_slope=0.0)
+            u2f = ctx.u2_flipped if ctx.u2_flipped is not None else wino_filter(w2, True)
+            (dz1,) = wino_conv3x3([dz2], u2f, Cm, gates=[y1], gate_slope=0.0)
             if need[2]:
                 dw2 = wino_wgrad([y1], [dz2], w2)
         else:

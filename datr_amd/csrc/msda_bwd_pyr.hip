@@ -63,6 +63,9 @@ extern "C" void datr_probe_pyr_bwd_phase_cycles(unsigned long long *out, int res
 
 namespace {
 
+#ifndef PYRB_GO_AUX
+#define PYRB_GO_AUX 0      // cache policy of the grad_out row loads (2 = non-temporal: each row is read by one workgroup)
+#endif
 #ifndef PYRB_INFLIGHT
 #define PYRB_INFLIGHT 8
 #endif
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
         const unsigned off = slot_ < nq ? (unsigned)decode(slot_) * row_stride + (unsigned)(lane & 7) * 16u
                                         : kOutOfRange;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(osrc, reinterpret_cast<lds_void *>(kGoOff + s0 * kRowBytes),
-                                                 16, (int)off, 0, 0, 0);
+                                                 16, (int)off, 0, 0, PYRB_GO_AUX);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

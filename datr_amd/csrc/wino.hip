@@ -331,8 +331,11 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
 // U[pos][Cin/8][Cout][8] = G g G^T of every (ci, co) filter, the 8 channels of a block in the order the MFMA
 // lanes consume them ([lane half][4-channel chunk of the block][k-step]: channel j = 4 h + 2 lhi + m sits at
 // 4 lhi + 2 h + m); flip = the data-gradient filter (taps mirrored; the caller swaps the channel strides)
+// Uf (may be null) = the data-gradient filter of the SAME weight from the same launch: mirroring the taps permutes
+// the transform rows / columns by (3, 1, 2, 0) -- G flip(g) G^T = P (G g G^T) P -- so every product computed here
+// is also an element of the flipped transform, with the channel roles swapped.
 __global__ void wino_weights(const float *__restrict__ w, long s_co, long s_ci, long s_r, long s_s, int flip,
-                             int Cin, int Cout, float *__restrict__ U)
+                             int Cin, int Cout, float *__restrict__ U, float *__restrict__ Uf)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Cin * Cout) return;
@@ -365,6 +368,12 @@ __global__ void wino_weights(const float *__restrict__ w, long s_co, long s_ci, 
             const float sg = ((xi == 3) != (nu == 3)) ? -1.f : 1.f;
             const int j = ci % CK8;
             U[(((size_t)pos * nchunks + ci / CK8) * Cout + co) * 8 + ((j & 3) >> 1) * 4 + (j >> 2) * 2 + (j & 1)] = sg * u[nu];
+            if (Uf) {                              // input channels of the data gradient = co, output channels = ci
+                const int xf = xi == 0 ? 3 : xi == 3 ? 0 : xi, nf = nu == 0 ? 3 : nu == 3 ? 0 : nu;
+                const float sf = ((xf == 3) != (nf == 3)) ? -1.f : 1.f;
+                const int jf = co % CK8;
+                Uf[(((size_t)(xf * 4 + nf) * (Cout / CK8) + co / CK8) * Cin + ci) * 8 + ((jf & 3) >> 1) * 4 + (jf >> 2) * 2 + (jf & 1)] = sf * u[nu];
+            }
         }
     }
 }
@@ -377,7 +386,17 @@ extern "C" int datr_wino_weights_f32(const float *w, int64_t Cout, int64_t Cin, 
     if (Cin % CK8 != 0 || Cout % BN != 0 || Cin * Cout > 0x7fffffffLL) return DATR_EUNSUPPORTED;
     const int total = (int)(Cin * Cout);
     hipLaunchKernelGGL(wino_weights, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (long)s_co,
-                       (long)s_ci, (long)s_r, (long)s_s, flip, (int)Cin, (int)Cout, u);
+                       (long)s_ci, (long)s_r, (long)s_s, flip, (int)Cin, (int)Cout, u, (float *)nullptr);
+    return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+extern "C" int datr_wino_weights_pair_f32(const float *w, int64_t Cout, int64_t Cin, int64_t s_co, int64_t s_ci,
+                                          int64_t s_r, int64_t s_s, float *u, float *u_flip, void *stream) {
+    if (!w || !u || !u_flip || Cin <= 0 || Cout <= 0) return DATR_EINVAL;
+    if (Cin % BN != 0 || Cout % BN != 0 || Cin * Cout > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+    const int total = (int)(Cin * Cout);
+    hipLaunchKernelGGL(wino_weights, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (long)s_co,
+                       (long)s_ci, (long)s_r, (long)s_s, 0, (int)Cin, (int)Cout, u, u_flip);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 

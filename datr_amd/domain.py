@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.autograd.function import once_differentiable
 
-from .wino import _nhwc, wino_conv3x3, wino_filter, wino_wgrad
+from .wino import _nhwc, wino_conv3x3, wino_filter, wino_filters, wino_wgrad
 
 
 def _c1_levels(xs, ys, dxs=None):
@@ -109,9 +109,13 @@ class _DImgPyramid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w1, b1, w2, b2, w3, b3, wc, bc, *xs):
         xs = [_nhwc(x) for x in xs]
-        a1 = wino_conv3x3(xs, wino_filter(w1), w1.shape[0], shift=b1, slope=_DImgPyramid.SLOPE)
-        a2 = wino_conv3x3(a1, wino_filter(w2), w2.shape[0], shift=b2, slope=_DImgPyramid.SLOPE)
-        a3 = wino_conv3x3(a2, wino_filter(w3), w3.shape[0], shift=b3, slope=_DImgPyramid.SLOPE)
+        # forward and data-gradient filters of a layer from one launch (kept for backward)
+        bwd = any(ctx.needs_input_grad)
+        (u1, f1), (u2, f2), (u3, f3) = (wino_filters(w, bwd) for w in (w1, w2, w3))
+        ctx.flipped = (f1, f2, f3)
+        a1 = wino_conv3x3(xs, u1, w1.shape[0], shift=b1, slope=_DImgPyramid.SLOPE)
+        a2 = wino_conv3x3(a1, u2, w2.shape[0], shift=b2, slope=_DImgPyramid.SLOPE)
+        a3 = wino_conv3x3(a2, u3, w3.shape[0], shift=b3, slope=_DImgPyramid.SLOPE)
         ctx.own_classifier = OWN_CLASSIFIER and wc.shape[:2] == (1, 128) and all(a.shape[1] == 128 for a in a3)
         outs = classifier_forward(a3, wc, bc) if ctx.own_classifier else [F.conv2d(a, wc, bc, padding=1) for a in a3]
         ctx.save_for_backward(w1, w2, w3, wc, *xs, *a1, *a2, *a3)
@@ -159,13 +163,14 @@ class _DImgPyramid(torch.autograd.Function):
             dwc = gw if dwc is None else dwc.add_(gw)
             dbc = gb if dbc is None else dbc.add_(gb)
         dw3, db3 = wgrad(dz3, a2, w3)
-        dz2 = wino_conv3x3(dz3, wino_filter(w3, True), w3.shape[1], gates=a2, gate_slope=slope)
+        f1, f2, f3 = (f if f is not None else wino_filter(w, True) for f, w in zip(ctx.flipped, (w1, w2, w3)))
+        dz2 = wino_conv3x3(dz3, f3, w3.shape[1], gates=a2, gate_slope=slope)
         dw2, db2 = wgrad(dz2, a1, w2)
-        dz1 = wino_conv3x3(dz2, wino_filter(w2, True), w2.shape[1], gates=a1, gate_slope=slope)
+        dz1 = wino_conv3x3(dz2, f2, w2.shape[1], gates=a1, gate_slope=slope)
         dw1, db1 = wgrad(dz1, xs, w1)
         dxs = [None] * n
         if any(ctx.needs_input_grad[8:]):
-            dxs = wino_conv3x3(dz1, wino_filter(w1, True), w1.shape[1], out_scale=-1.0)   # GRL
+            dxs = wino_conv3x3(dz1, f1, w1.shape[1], out_scale=-1.0)   # GRL
         return (dw1, db1, dw2, db2, dw3, db3, dwc, dbc, *dxs)
 
 

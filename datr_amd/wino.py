@@ -45,6 +45,32 @@ def wino_filter(w: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
     return u
 
 
+def wino_filters(w: torch.Tensor, want_flipped: bool = True):
+    """(forward filter, data-gradient filter or None): one launch for both where the channel counts admit it."""
+    if want_flipped:
+        pair = wino_filter_pair(w)
+        if pair is not None:
+            return pair
+    return wino_filter(w), None
+
+
+def wino_filter_pair(w: torch.Tensor):
+    """(wino_filter(w), wino_filter(w, data_gradient=True)) from ONE launch -- the mirrored filter's transform is a
+    permutation of the plain one's -- or None when the channel counts do not admit both (multiples of 64)."""
+    from . import _native
+    co, ci = w.shape[:2]
+    if co % 64 or ci % 64:
+        return None
+    s = w.stride()
+    u = torch.empty(16 * ci * co, device=w.device, dtype=torch.float32)
+    uf = torch.empty(16 * ci * co, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        rc = _native.lib.datr_wino_weights_pair_f32(w.data_ptr(), co, ci, s[0], s[1], s[2], s[3], u.data_ptr(),
+                                                    uf.data_ptr(), _native.current_stream_ptr(w.device))
+    _native.check(rc, "wino_weights_pair")
+    return u, uf
+
+
 def wino_conv3x3(xs, u: torch.Tensor, cout: int, shift=None, scale=None, slope: float = 1.0, gates=None,
                  gate_slope: float = 1.0, out_scale: float = 1.0):
     """3x3 / stride 1 / pad 1 convolution of every level in `xs` (channels_last [N, Cin, H, W] device

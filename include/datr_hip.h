@@ -237,6 +237,10 @@ int datr_affine_act_backward2_f32(const float *dy, const float *dy2, const float
 typedef struct { const float *x; float *y; const float *gate; int64_t H, W; } datr_wino_level;
 int datr_wino_weights_f32(const float *w, int64_t Cout, int64_t Cin, int64_t s_co, int64_t s_ci,
                           int64_t s_r, int64_t s_s, int flip, float *u, void *stream);
+/* Both filters of a layer from one launch: u for the forward, u_flip for the data gradient (= what
+ * datr_wino_weights_f32 gives with the channel strides swapped and flip = 1); Cin % 64 == 0 and Cout % 64 == 0. */
+int datr_wino_weights_pair_f32(const float *w, int64_t Cout, int64_t Cin, int64_t s_co, int64_t s_ci, int64_t s_r,
+                               int64_t s_s, float *u, float *u_flip, void *stream);
 int datr_conv3x3_wino_nhwc_f32(const datr_wino_level *levels, int64_t nlevels, int64_t N, int64_t Cin,
                                int64_t Cout, const float *u, const float *scale, const float *shift,
                                float slope, float gate_slope, float out_scale, void *stream);

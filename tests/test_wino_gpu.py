@@ -328,3 +328,21 @@ def test_one_channel_classifier_matches_float64_autograd(sizes):
     for dz, g in zip(dzs, grads[2:]):
         assert dz.is_contiguous(memory_format=torch.channels_last) or dz.shape[2] * dz.shape[3] == 1
         torch.testing.assert_close(dz.double(), g, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("co,ci", [(64, 64), (128, 256), (512, 512)])
+def test_filter_pair_equals_the_two_separate_transforms(co, ci):
+    """datr_wino_weights_pair_f32: the forward and the data-gradient filter of a weight from one launch (mirroring
+    the taps permutes the transform's rows / columns): the forward one bitwise, the mirrored one up to the order of
+    the three-term sums (w0 + w1 + w2 against w2 + w1 + w0)."""
+    from datr_amd import wino
+    dev = torch.device("cuda:0")
+    torch.manual_seed(co + ci)
+    w = torch.randn(co, ci, 3, 3, device=dev)
+    u, uf = wino.wino_filter_pair(w)
+    assert torch.equal(u, wino.wino_filter(w))
+    torch.testing.assert_close(uf, wino.wino_filter(w, True), rtol=1e-6, atol=1e-6)
+    wt = w.permute(1, 0, 2, 3)                      # a strided weight
+    u2, uf2 = wino.wino_filter_pair(wt)
+    assert torch.equal(u2, wino.wino_filter(wt))
+    torch.testing.assert_close(uf2, wino.wino_filter(wt, True), rtol=1e-6, atol=1e-6)
