@@ -34,6 +34,9 @@
 
 #include "datr_hip.h"
 
+#ifndef WGRAD_NT_PARTIALS
+#define WGRAD_NT_PARTIALS 0   // non-temporal partial-sum stores: measured SLOWER (layer2 147 -> 164 us): the fold reads them next
+#endif
 #ifndef WGRAD_ABLATE
 #define WGRAD_ABLATE 0     // development only (wrong results): 1 no fetch (16 / 32: none by the patch / dY waves), 2 no transform, 4 no multiply, 8 no loop barrier
 #endif
@@ -243,7 +246,11 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = i * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+#if WGRAD_NT_PARTIALS
+                    __builtin_nontemporal_store(acc[p][i][j][r], &out[((size_t)(PW * wave + p) * Cout + co0 + row) * Cin + ci0 + j * 32 + l31]);
+#else
                     out[((size_t)(PW * wave + p) * Cout + co0 + row) * Cin + ci0 + j * 32 + l31] = acc[p][i][j][r];
+#endif
                 }
 }
 
