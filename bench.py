@@ -550,6 +550,11 @@ def main():
                          "MIOpen's measured-fastest fp32 solvers want; same arithmetic)")
     ap.add_argument("--no-tuned-gemm", dest="tuned_gemm", action="store_false",
                     help="leave hipBLASLt on its default heuristic (datr_amd/tuning)")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="TEST flag: accept DATR_DIST_BACKEND=gloo for --gpus N > 1, so that the multi-rank leg "
+                         "(self-relaunch, rank-0-only line, max-over-ranks time, per-rank batches) can be "
+                         "executed by ranks SHARING one GPU (tests/test_bench_gpu.py); the line then says "
+                         "config.dist_backend = gloo and is not a scaling measurement")
     ap.add_argument("--stage", choices=["burn-in", "source-only", "teacher"], default="burn-in",
                     help="teacher: the teacher-student stage (BASELINE config 5) on one GPU; "
                          "source-only: BASELINE config 2 read literally -- the burn-in step with the "
@@ -569,8 +574,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
-        assert dist.is_initialized() and dist.get_world_size() == world and dist.get_backend() == "nccl", \
-            "the multi-GPU bench runs over RCCL (torch.distributed backend 'nccl')"
+        assert dist.is_initialized() and dist.get_world_size() == world, "process group not up"
+        assert dist.get_backend() == "nccl" or (args.allow_gloo and dist.get_backend() == "gloo"), \
+            "the multi-GPU bench runs over RCCL (torch.distributed backend 'nccl'); --allow-gloo is for tests"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -669,7 +675,10 @@ def main():
                        "images_per_gpu": per_gpu, "global_batch_pairs": args.batch * world,
                        "parallelism": f"dp{world}", "num_gt_per_image": args.num_gt,
                        "grad_reducer": state.reducer is not None,
-                       "rccl_world": dist.get_world_size() if dist.is_initialized() else 1},
+                       "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
+                       "dist_backend": dist.get_backend() if dist.is_initialized() else None,
+                       "batch_seeds_rank0": [1 + 1000 * i for i in range(len(pool))],
+                       "batch_seed_rule": "1 + 7 * rank + 1000 * i (every rank trains on different batches)"},
             "pairs_per_sec": round(images / elapsed / (1 if source_only else 2), 3),
             "ms_per_step_each": [round(v, 1) for v in per_step_raw] if os.environ.get("DATR_BENCH_PER_STEP") else None,
             "padded_batch_ms_per_step": padded_ms,

@@ -466,3 +466,92 @@ def test_selftraining_epoch_function_world4_many_buckets_rank_dependent_pseudo_l
     port = _free_port()
     mp.spawn(_selftrain_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(4))
+
+
+# ---------------------------------------------------------------------------------------------
+# eight ranks (the size of the driver's SCALE run), the real detector, two ranks without boxes
+# ---------------------------------------------------------------------------------------------
+def _world8_worker(rank, world, port, tmp):
+    import copy
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import synth
+    from helpers import build_model
+    from datr_amd import criterion as crit_mod, msda
+    from datr_amd.config import get_param_dict
+    from datr_amd.dist import GradAllReducer, attach_reducer, init_distributed
+    from datr_amd.engine import train_one_epoch
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    from oracle import focal_oracle, msda_oracle as O
+    msda.ms_deform_attn_forward = lambda v, sh, lsi, loc, a, step: O.msda_forward(v, sh, lsi, loc, a)
+    msda.ms_deform_attn_backward = lambda v, sh, lsi, loc, a, go, step: \
+        list(O.msda_backward(v, sh, lsi, loc, a, go))
+    crit_mod.focal_loss_sums = focal_oracle.focal_sums_torch
+    init_distributed(backend="gloo")
+
+    args, model, criterion, _ = build_model()
+    with torch.no_grad():                         # ranks start from different weights (main.py:138)
+        g = torch.Generator().manual_seed(1000 + rank)
+        for p in model.parameters():
+            p.add_(0.01 * rank * torch.randn(p.shape, generator=g))
+    red = GradAllReducer(model, bucket_mb=24.0, first_bucket_mb=2.0)     # constructor broadcast
+    attach_reducer(model, red)
+    assert red.world == 8 and len(red.buckets) >= 8, len(red.buckets)
+    w = model.transformer.level_embed.detach().clone()
+    dist.broadcast(w, 0)
+    assert torch.equal(w, model.transformer.level_embed), "rank 0's weights on every rank"
+    ref = copy.deepcopy(model)
+    attach_reducer(ref, False)
+
+    boxless = rank in (2, 5)
+    imgs, targets = synth.synth_batch(seed=11 + rank, sizes=((192, 240), (184, 232)),
+                                      num_gt=0 if boxless else 1 + rank % 3)
+    batch = (nested_tensor_from_tensor_list(imgs), tuple(targets), None, None)
+    opt = torch.optim.SGD(get_param_dict(args, model), lr=0.0)           # gradients only
+    torch.manual_seed(300 + rank)                                         # CDN noise
+    stats = train_one_epoch(model, criterion, [batch], opt, torch.device("cpu"), 0, max_norm=0, args=args)
+    assert stats["loss"] == stats["loss"]
+    opt_ref = torch.optim.SGD(get_param_dict(args, ref), lr=0.0)
+    torch.manual_seed(300 + rank)
+    train_one_epoch(ref, criterion, [batch], opt_ref, torch.device("cpu"), 0, max_norm=0, args=args)
+
+    worst, missing = 0.0, 0
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if not p.requires_grad:
+            continue
+        missing += q.grad is None
+        local = torch.zeros_like(q) if q.grad is None else q.grad.clone()
+        dist.all_reduce(local)
+        local /= world
+        assert p.grad is not None, n
+        scale = float(local.abs().max()) + 1e-12
+        err = float((p.grad - local).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 1e-4, (n, err)
+    sizes = torch.tensor([b.numel for b in red.buckets])
+    dist.broadcast(sizes, 0)
+    assert sizes.tolist() == [b.numel for b in red.buckets], "bucket layout differs between ranks"
+    flags = red.used_flags().clone()
+    f0 = flags.clone()
+    dist.broadcast(f0, 0)
+    assert torch.equal(f0, flags), "MAX-reduced used flags are the same on every rank"
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write(f"ok {worst:.2e} buckets {len(red.buckets)} missing {missing}")
+
+
+def test_epoch_function_world8_two_boxless_ranks(tmp_path):
+    """the reducer at the world size of the driver's SCALE run -- eight gloo ranks with
+    the real detector (tiny images) through `engine.train_one_epoch`, >= 8 gradient buckets, ranks 2 and 5
+    WITHOUT any box (no de-noising queries, no matched pairs: fewer gradients); every rank issues the same
+    collectives in the same order and ends with the average of the eight single-process gradients and the
+    same used-parameter flags."""
+    port = _free_port()
+    mp.spawn(_world8_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(8))
