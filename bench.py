@@ -288,6 +288,26 @@ def split_bf16_step_ms(state, pool, steps):
         del os.environ["DATR_GEMM_SPLIT_BF16"]
 
 
+def config1_device_step(state, steps=6):
+    """BASELINE configs[0]'s shape on the HIP path, beside the CPU leg's number at the same shape: ONE source
+    image 640 x 640, DA branch off (S = 8 500), `steps` training steps through engine.train_one_epoch after 4
+    warm-up steps, with the timed run's model / optimizer (run after every other measurement)."""
+    was = state.model.domain_adaptation
+    state.model.domain_adaptation = False
+    try:
+        b = synthetic_batch(1, 640, 640, 5, state.device, seed=1, source_only=True)
+        run_steps(state, [b] * 4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(state, [b] * steps)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        state.model.domain_adaptation = was
+    return {"value": round(1e3 / ms, 2), "unit": "images/s", "ms_per_step": round(ms, 2), "steps": steps,
+            "sample": "the same step (1 source image 640x640, DA branch off) on the HIP path, one MI355X"}
+
+
 def teacher_student_stage(args, device):
     """BASELINE config 5 on one GPU: datr_amd.engine.train_one_epoch_with_self_training (the
     reference's epoch function, engine.py:146-342) on synthetic batches -- EMA teacher forward
@@ -396,6 +416,9 @@ def mfma_utilisation(device, rows, experiments=True):
            "kernel": f"gemm_f32_kernel (own, csrc/gemm_f32.hip): FFN hidden gradient with ReLU mask + bias-sum "
                      f"epilogue, M={rows} N=2048 K=256, measured live",
            "own_gemm_without_epilogue_tflops": round(own_plain, 1),
+           # rounds 1-3 reported the harmonic mean of the three library FFN GEMMs under `achieved`; kept under its
+           # own name so that round-to-round numbers stay comparable
+           "r01_r03_headline_mean_of_three_library_gemms_tflops": round(lib_mean, 1),
            "library_gemm": {"achieved": round(lib_mean, 1), "frac": round(lib_mean / MFMA_FP32_PEAK_TFLOPS, 4),
                             "kernel": f"encoder FFN GEMMs, M={rows} N=2048 K=256 (hipBLASLt / rocBLAS, fp32), measured live",
                             "per_gemm_tflops": {k: round(v, 1) for k, v in lib.items()}},
@@ -509,6 +532,15 @@ def cpu_baseline(msda_gpu_us=None):
                                               f"640x640, DA branch off (BASELINE config 1 as stated), "
                                               f"{dt1:.1f} s"},
             "msda_op": msda_cpu_ops(msda_gpu_us)}
+
+
+def _gemm_backend(args):
+    """Who ran the large linear / FFN / 1x1-convolution GEMMs of the timed step (datr_amd.gemm.BACKEND)."""
+    from datr_amd import gemm
+    if not args.tuned_gemm:
+        return "hipBLASLt default heuristic (--no-tuned-gemm)"
+    return {"library": "hipBLASLt", "own": "own fp32-MFMA GEMM family (csrc/gemm_f32.hip)"}[gemm.BACKEND] + \
+        f" [{gemm.BACKEND_REASON}]"
 
 
 def relaunch_with_ranks(n):
@@ -675,6 +707,7 @@ def main():
                        "images_per_gpu": per_gpu, "global_batch_pairs": args.batch * world,
                        "parallelism": f"dp{world}", "num_gt_per_image": args.num_gt,
                        "grad_reducer": state.reducer is not None,
+                       "gemm_backend": _gemm_backend(args),
                        "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
                        "dist_backend": dist.get_backend() if dist.is_initialized() else None,
                        "batch_seeds_rank0": [1 + 1000 * i for i in range(len(pool))],
@@ -712,11 +745,14 @@ def main():
                                                   "SQ_VALU_MFMA_BUSY_CYCLES of every launch of five steps, "
                                                   "tools/pmc_step_mfma.sh) -- not measured in this run")
         if world == 1 and not args.no_cpu_baseline and not source_only:
+            timer.enabled = False
+            hip_c1 = config1_device_step(state)
             if dist.is_initialized():       # one-rank RCCL mode: the CPU leg must not see a NCCL group
                 dist.destroy_process_group()
             # GPU time of the op at the CPU leg's shape (N=2): the merged N=4 launch / 2
             gpu_us = roof["mean_us"] * 2 / timer.shape[0] if roof else None
             line["cpu_baseline"] = cpu_baseline(gpu_us)
+            line["cpu_baseline"]["config1_source_only"]["hip_same_shape"] = hip_c1
         # RCCL writes its version banner through C stdio, which sits in a buffer when stdout is a pipe
         # and would come out AFTER this line at exit: push it out first, the JSON line stays the last one
         import ctypes

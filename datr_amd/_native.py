@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DATR_HIP_LIB points at an alternative build of the same ABI (e.g. the -DDATR_PROBE build used
 # for kernel ablations); there is still no non-native fallback.
 LIB_PATH = os.environ.get("DATR_HIP_LIB") or os.path.join(_HERE, "lib", "libdatr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i64 = ctypes.c_int64
 _vp = ctypes.c_void_p

@@ -63,6 +63,9 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
 
 
+_CAPTURE = None
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -120,6 +123,7 @@ class Bottleneck(nn.Module):
             out = pointwise.conv1x1(x, folded[0], self.bn1.scale_shift()[1], relu=True)
         if out is None:
             out = frozen_bn_act(self.conv1(x), *self.bn1.scale_shift(), relu=True)
+        act1 = out
         out2 = None
         if self.conv2.stride == (1, 1):
             # 3x3 / stride 1 + frozen BN + ReLU: one Winograd/MFMA launch (csrc/wino.hip)
@@ -137,7 +141,10 @@ class Bottleneck(nn.Module):
             y3 = self.conv3(out)
         if self.pair_out and self.training:
             return frozen_bn_act(y3, *self.bn3.scale_shift(), residual=identity, relu=True, twice=True)
-        return frozen_bn_act(y3, *self.bn3.scale_shift(), residual=identity, relu=True)
+        y = frozen_bn_act(y3, *self.bn3.scale_shift(), residual=identity, relu=True)
+        if _CAPTURE is not None:          # tests: the three activations, so that a float64 reference can open
+            _CAPTURE.append((act1, out, y))   # its ReLUs where this run did (as datr_amd.bottleneck._CAPTURE)
+        return y
 
     def fold_pairs(self):
         """(slot, weight, frozen scale) of the 1x1 convolutions whose batch norm is folded into the GEMM:

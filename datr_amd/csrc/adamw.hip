@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kThreads) void adamw_update(const datr_adamw_tensor
 {
     const datr_adamw_piece pc = pieces[blockIdx.x];
     const datr_adamw_tensor t = tensors[pc.tensor];
-    if (used && used[t.used_index] == 0) return;
+    if (used && t.used_index >= 0 && used[t.used_index] == 0) return;   // used_index < 0: no flag for this tensor, always updated
     const float coef = clip_coef ? *clip_coef : 1.f;
     const double tstep = (double)*t.step + 1.0;
     const double bc1 = 1.0 - pow(b1d, tstep), bc2 = 1.0 - pow(b2d, tstep);
@@ -83,7 +83,7 @@ __global__ void adamw_count(const datr_adamw_tensor *__restrict__ tensors, int n
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntensors) return;
     const datr_adamw_tensor t = tensors[i];
-    if (used && used[t.used_index] == 0) return;
+    if (used && t.used_index >= 0 && used[t.used_index] == 0) return;   // used_index < 0: no flag for this tensor, always updated
     *t.step += 1.f;
 }
 

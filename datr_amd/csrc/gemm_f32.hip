@@ -406,8 +406,11 @@ __global__ __launch_bounds__(kThreads, BKT == 16 ? 4 : 2) void gemm_f32_kernel(c
                 for (int e = 0; e < EB; ++e) {
                     const int m = mb + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
                     float v = acc[i][j][e0 + e] * sc + sh + rv[e];
-                    v = fmaxf(v, relu_floor);
-                    v = gv[e] > gate_thr ? v : 0.f;
+                    // NaN travels as through torch.relu / threshold_backward (fmaxf would return the floor for a NaN
+                    // accumulator, `gate > thr` would drop the gradient under a NaN gate): the loss guard of the
+                    // training loop (engine.py:81-84) must see a diverged run
+                    v = v < relu_floor ? relu_floor : v;
+                    v = gv[e] <= gate_thr ? 0.f : v;
                     if (want_cs) cs[j] += m < a.M ? v : 0.f;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), cr,
                                                           (int)(colb[j] + (unsigned)m * (unsigned)a.ldc * 4u), 0, GEMM_EPI_AUX);

@@ -545,7 +545,7 @@ const char *datr_strerror(int code) {
     }
 }
 
-int datr_abi_version(void) { return 1; }
+int datr_abi_version(void) { return 2; }
 
 int datr_msda_uses_fast_path(int64_t S, int64_t M, int64_t D, int64_t L, int64_t P) {
     return fast_lpr(S, M, D, L, P, 48) != 0;

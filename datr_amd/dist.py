@@ -157,6 +157,7 @@ class GradAllReducer:
         pin = self.device.type == "cuda"
         self._used_stage = [torch.zeros(n, dtype=torch.int32, pin_memory=pin) for _ in range(3)]
         self._used_turn = 0
+        self._used_events = [None] * len(self._used_stage)      # the device copy that last read each staging buffer
         self._used = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._used_work = None
 
@@ -230,17 +231,19 @@ class GradAllReducer:
             self._launch(self.buckets[self._next])
             self._next += 1
 
-    def _gather(self, b: _Bucket, stream=None):
+    def _gather(self, b: _Bucket, stream=None, mark: bool = True):
         """Move the gradients autograd produced into the flat buffer with ONE multi-tensor copy and
         make the buffer slices the parameters' .grad.  (Pre-attaching the slices as .grad instead
         makes autograd ACCUMULATE into them: one add kernel per parameter, 300 launches and 1.4 ms
         per step.)  Parameters without a gradient this step keep their zeroed slice.
-        `stream`: the stream the copy runs on when gradients may come from another one."""
+        `stream`: the stream the copy runs on when gradients may come from another one.
+        `mark`: record "a gradient was produced" in this step's staging buffer (False when finish() re-homes
+        already reduced gradients: the buffer is then on its way to the device and must not be rewritten)."""
         dst, src = [], []
         stage = self._used_stage[self._used_turn]
         for p, v in zip(b.params, b.views):
             g = p.grad
-            if g is not None:
+            if g is not None and mark:
                 stage[self._index[p]] = 1
             if g is not None and g.data_ptr() != v.data_ptr():
                 if g.shape != v.shape or g.dtype != v.dtype or g.device != v.device:
@@ -299,6 +302,10 @@ class GradAllReducer:
                 p.grad = None
         self._next = 0
         self._used_turn = (self._used_turn + 1) % len(self._used_stage)
+        ev = self._used_events[self._used_turn]
+        if ev is not None:              # the copy that read this buffer two steps ago: long done, unless a caller's
+            ev.synchronize()            # loop never waits for the device
+            self._used_events[self._used_turn] = None
         self._used_stage[self._used_turn].zero_()
 
     def finish(self):
@@ -311,6 +318,8 @@ class GradAllReducer:
         self._next = len(self.buckets)
         # every bucket is gathered: this rank's used flags are complete
         self._used.copy_(self._used_stage[self._used_turn], non_blocking=True)
+        if self._used.is_cuda:
+            self._used_events[self._used_turn] = torch.cuda.current_stream(self.device).record_event()
         if self.world > 1 or FORCE_COLLECTIVES:
             self._used_work = dist.all_reduce(self._used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
@@ -326,11 +335,9 @@ class GradAllReducer:
             self._used_work.wait()
             self._used_work = None
         if self._arrival is not None:
-            stage = self._used_stage[self._used_turn].clone()
             self._rebuild_from_first_step()
-            for b in self.buckets:      # re-home this step's (already reduced) gradients
-                self._gather(b)
-            self._used_stage[self._used_turn].copy_(stage)     # the re-homing saw every kept gradient
+            for b in self.buckets:      # re-home this step's (already reduced) gradients; the used flags are on
+                self._gather(b, mark=False)     # their way to the device: the staging buffer is not touched
 
     def used_flags(self) -> torch.Tensor:
         """int32 device tensor, one entry per parameter of `self.params`: 1 = some rank produced a

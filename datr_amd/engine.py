@@ -74,9 +74,13 @@ def _settle_garbage_collector(steps_done: int = 0) -> None:
     optimizer's state), collect and FREEZE them (`gc.freeze`): a full collection then walks only what was
     created since.  Without it the cyclic collector's oldest generation comes round every ~50 steps and
     walks everything -- measured 80-90 ms of host time in one step, during which the device runs dry
-    (tools/probes/monitor_hiccup2.py: steps of 162 ms among 76 ms ones; none with the collector off)."""
+    (tools/probes/monitor_hiccup2.py: steps of 162 ms among 76 ms ones; none with the collector off).
+    This is a PROCESS-GLOBAL side effect of calling the epoch functions (objects alive at the third step are never
+    examined by the cyclic collector again; reference counting still frees them): DATR_FREEZE_GC=0 switches it
+    off (INTEGRATION.md)."""
+    import os
     _GC_FROZEN[1] += 1
-    if _GC_FROZEN[1] == 3 and not _GC_FROZEN[0]:
+    if _GC_FROZEN[1] == 3 and not _GC_FROZEN[0] and os.environ.get("DATR_FREEZE_GC", "1") != "0":
         import gc
         gc.collect()
         gc.freeze()

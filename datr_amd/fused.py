@@ -189,11 +189,36 @@ FFN_OWN_HIDDEN = os.environ.get("DATR_FFN_OWN_HIDDEN", "0") != "0"
 def _ffn_hidden(x2: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
     """h = relu(x2 W1^T + b1): the library GEMM with its bias + ReLU epilogue, or (DATR_FFN_OWN_HIDDEN=1, an A/B
     switch) the own family's NT form with the same epilogue."""
-    if FFN_OWN_HIDDEN and x2.shape[0] >= FFN_FUSED_DZ_MIN_ROWS and x2.is_contiguous() and w1.is_contiguous() \
-            and x2.shape[1] % 32 == 0 and w1.shape[0] % 4 == 0:
-        from . import gemm
+    from . import gemm
+    if (FFN_OWN_HIDDEN and x2.shape[0] >= FFN_FUSED_DZ_MIN_ROWS and x2.is_contiguous() and w1.is_contiguous()
+            and x2.shape[1] % 32 == 0 and w1.shape[0] % 4 == 0) or gemm.own_big(x2, w1):
         return gemm.gemm_nt(x2, w1, shift=b1.contiguous(), relu=True)
     return torch._addmm_activation(b1, x2, w1.t(), use_gelu=False)
+
+
+def _linear_fwd(x2: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """x2 W^T + b: the library GEMM, or the own NT form when the large products are the own family's
+    (datr_amd.gemm.BACKEND: no valid hipBLASLt selections for this installation)."""
+    from . import gemm
+    if gemm.own_big(x2, w) and (out is None or gemm.own_big(out)):
+        return gemm.gemm_nt(x2, w, shift=b.contiguous(), out=out)
+    return torch.addmm(b, x2, w.t()) if out is None else torch.addmm(b, x2, w.t(), out=out)
+
+
+def _dgrad(dy2: torch.Tensor, w: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+    """dy2 W (+ residual): the data gradient of a linear layer, library GEMM or the own NN form."""
+    from . import gemm
+    if gemm.own_big(dy2, w) and (residual is None or gemm.own_big(residual)):
+        return gemm.gemm_nn(dy2, w, residual=residual)
+    return dy2.mm(w) if residual is None else torch.addmm(residual, dy2, w)
+
+
+def _wgrad_mm(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dy2^T x2: library GEMM or the own split-K TN form."""
+    from . import gemm
+    if gemm.own_big(dy2, x2):
+        return gemm.gemm_tn(dy2, x2)
+    return dy2.t().mm(x2)
 
 
 def _ffn_wgrad(dy2: torch.Tensor, x2: torch.Tensor, want_w: bool, want_b: bool):
@@ -206,7 +231,10 @@ def _ffn_wgrad(dy2: torch.Tensor, x2: torch.Tensor, want_w: bool, want_b: bool):
         if want_b:
             return gemm.gemm_tn(dy2, x2, bias_grad=True)
         return gemm.gemm_tn(dy2, x2), None
-    dw = dy2.t().mm(x2) if want_w else None
+    from . import gemm
+    if want_w and want_b and gemm.own_big(dy2, x2):
+        return gemm.gemm_tn(dy2, x2, bias_grad=True)
+    dw = _wgrad_mm(dy2, x2) if want_w else None
     db = column_sums(dy2) if want_b else None
     return dw, db
 
@@ -227,8 +255,8 @@ class _FFNRelu(Function):
     def forward(ctx, x, w1, b1, w2, b2):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        h = torch._addmm_activation(b1, x2, w1.t(), use_gelu=False)
-        y = torch.addmm(b2, h, w2.t())
+        h = _ffn_hidden(x2, w1, b1)
+        y = _linear_fwd(h, w2, b2)
         ctx.save_for_backward(x2, h, w1, w2)
         ctx.shape = shape
         return y.view(*shape[:-1], w2.shape[0])
@@ -245,7 +273,7 @@ class _FFNRelu(Function):
         dw2, db2 = _ffn_wgrad(dy2, h, need[3], need[4])
         dh, db1 = _ffn_hidden_gradient(dy2, w2, h)
         dw1 = _ffn_wgrad(dh, x2, need[1], False)[0]
-        dx = dh.mm(w1).view(ctx.shape) if need[0] else None
+        dx = _dgrad(dh, w1).view(ctx.shape) if need[0] else None
         return dx, dw1, (db1 if need[2] else None), dw2, db2
 
 
@@ -331,7 +359,7 @@ class _FFNAddNorm(Function):
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         rows = x2.shape[0]
         h = _ffn_hidden(x2, w1, b1)
-        y = torch.addmm(b2, h, w2.t())
+        y = _linear_fwd(h, w2, b2)
         out = torch.empty_like(x2)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
@@ -367,7 +395,7 @@ class _FFNAddNorm(Function):
         dw2, db2 = _ffn_wgrad(dsum, h, need[3], need[4])
         dh, db1 = _ffn_hidden_gradient(dsum, w2, h)
         dw1 = _ffn_wgrad(dh, x2, need[1], False)[0]
-        dx = torch.addmm(dsum, dh, w1).view(ctx.shape) if need[0] else None
+        dx = _dgrad(dh, w1, residual=dsum).view(ctx.shape) if need[0] else None
         return (dx, dw1, db1 if need[2] else None, dw2, db2, dgamma if need[5] else None,
                 dbeta if need[6] else None, None)
 
@@ -586,7 +614,7 @@ class _LinearFn(Function):
         # the result is allocated in its final shape (the GEMM writes through a 2-d view of it): the
         # caller gets a tensor that is nobody's view and may hand it to an in-place op (msda._ZeroRows)
         out = torch.empty(*shape[:-1], w.shape[0], device=x.device, dtype=x.dtype)
-        torch.addmm(b, x2, w.t(), out=out.view(-1, w.shape[0]))
+        _linear_fwd(x2, w, b, out=out.view(-1, w.shape[0]))
         ctx.save_for_backward(x2, w)
         ctx.shape = shape
         return out
@@ -600,7 +628,7 @@ class _LinearFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         need = ctx.needs_input_grad
-        dx = dy2.mm(w).view(ctx.shape) if need[0] else None
+        dx = _dgrad(dy2, w).view(ctx.shape) if need[0] else None
         if need[1] and _own_wgrad_applies(dy2, x2):
             # weight gradient as the deterministic split-K product of the own GEMM family; the bias
             # gradient falls out of its A fragments (no column-sum launches)

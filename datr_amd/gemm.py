@@ -18,6 +18,37 @@ from . import _native
 NT, NN, TN = 0, 1, 2
 _workspaces = {}
 
+# Who runs the LARGE dense products of the linears / FFN / 1x1 convolutions (>= BIG_ROWS rows: the encoder's
+# 88 892-token GEMMs, the wide feature maps) that are hipBLASLt's by default:
+#   "library"  hipBLASLt with the per-shape selections of datr_amd/tuning (127-145 TF/s on those shapes), or its
+#              default heuristic when the caller asked for that (bench.py --no-tuned-gemm);
+#   "own"      this family (129-132 TF/s) -- chosen automatically by `tuning.enable()` when the selections file
+#              does not validate against the installed torch / hipBLASLt: the default heuristic then picks
+#              ~83 TF/s kernels for the FFN shapes (+12 ms per training step), the own kernels do not depend on
+#              any tuning artefact.  DATR_GEMM_BACKEND=own / library forces either side.
+BACKEND = "library"
+BACKEND_REASON = "default"
+BIG_ROWS = 16384
+
+
+def set_backend(name: str, reason: str) -> None:
+    global BACKEND, BACKEND_REASON
+    assert name in ("library", "own")
+    BACKEND, BACKEND_REASON = name, reason
+
+
+def own_big(*mats) -> bool:
+    """True when the large product over these row-major operands goes to the own family: backend "own", at
+    least BIG_ROWS rows in the first operand, every operand 2-d float32 on the device with a unit last stride,
+    16-byte aligned rows and a feature count that is a multiple of 32 (what every kernel form accepts)."""
+    if BACKEND != "own" or mats[0].shape[0] < BIG_ROWS:
+        return False
+    for t in mats:
+        if not (t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and t.shape[1] % 32 == 0
+                and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+            return False
+    return True
+
 
 def _workspace(device, stream: int, floats: int):
     """Scratch per (device, stream), grown on demand; the kernels of one stream run in order, so a

@@ -311,7 +311,7 @@ class _ValueProjN(Function):
     @once_differentiable
     @_amp_bwd
     def backward(ctx, *gs):
-        from .fused import column_sums
+        from .fused import _dgrad, _wgrad_mm, column_sums
         memory, *ws = ctx.saved_tensors
         n, slab = ctx.n, ctx.slab
         C = memory.shape[-1]
@@ -320,8 +320,8 @@ class _ValueProjN(Function):
         if all(w.shape[0] == C for w in ws) and slab.holds(gs, C):
             buf, slab.buf = slab.buf, None                # the next step gets a fresh buffer
             g2 = buf.view(-1, n * C)
-            dmem = g2.mm(torch.cat(ws, 0)).view_as(memory) if need[0] else None
-            dws = g2.t().mm(m2).split(C, 0)
+            dmem = _dgrad(g2, torch.cat(ws, 0)).view_as(memory) if need[0] else None
+            dws = _wgrad_mm(g2, m2).split(C, 0)
             dbs = column_sums(g2).split(C, 0)
         else:
             dmem, dws, dbs = None, [], []

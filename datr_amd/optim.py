@@ -86,9 +86,16 @@ class FusedClipAdamW(torch.optim.Optimizer):
                     if not _same_layout(st[k], p):
                         st[k] = torch.empty_like(p).copy_(st[k])
                 dev = p.device
-                ui = -1 if self._index is None else self._index.get(id(p), -1)
+                # -1 = no used flag for this tensor (the kernel then always updates it); once an order is set a
+                # parameter missing from it would silently follow another parameter's flag: refuse
+                ui = -1
+                if self._index is not None:
+                    if id(p) not in self._index:
+                        raise KeyError("FusedClipAdamW: a parameter with a gradient is missing from the "
+                                       "set_used_order() list")
+                    ui = self._index[id(p)]
                 rows.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                             st["step"].data_ptr(), p.numel(), g["lr"], g["weight_decay"], max(ui, 0), 0))
+                             st["step"].data_ptr(), p.numel(), g["lr"], g["weight_decay"], ui, 0))
                 pieces += [(len(rows) - 1, off) for off in range(0, p.numel(), piece)]
         return rows, pieces, dev
 
@@ -100,10 +107,20 @@ class FusedClipAdamW(torch.optim.Optimizer):
         t = self._tables
         if t is None or t["key"] != key:
             arr = np.array(rows, dtype=_TENSOR_DT)
+
+            def upload(host):
+                # through pinned memory, asynchronously: a pageable source makes the copy a host synchronisation,
+                # and without the flat-bucket reducer the gradient pointers (hence the tables) change every step.
+                # (torch's pinned-memory allocator does not hand a freed block out again before the copies that read
+                # it have run: it records the stream of every non_blocking copy)
+                pin = torch.empty(host.shape, dtype=host.dtype, pin_memory=True)
+                pin.copy_(host)
+                return pin, pin.to(dev, non_blocking=True)
+            pin_t, dev_t = upload(torch.from_numpy(arr.view(np.uint8).reshape(-1)))
+            pin_p, dev_p = upload(torch.tensor(pieces, dtype=torch.int64).reshape(-1, 2))
             t = self._tables = {
                 "key": key, "n": len(rows), "npieces": len(pieces), "device": dev,
-                "tensors": torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev),
-                "pieces": torch.tensor(pieces, dtype=torch.int64).reshape(-1, 2).to(dev),
+                "tensors": dev_t, "pieces": dev_p, "pinned": (pin_t, pin_p),
                 "partial": torch.empty(len(pieces), dtype=torch.float32, device=dev),
                 "norm_coef": torch.empty(2, dtype=torch.float32, device=dev),
             }

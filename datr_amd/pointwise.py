@@ -47,7 +47,10 @@ class _Conv1x1(Function):
         N, C, H, W = x.shape
         co = w2.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(-1, C)                     # zero-copy for channels_last
-        if relu:
+        from . import gemm
+        if gemm.own_big(x2, w2):          # no valid hipBLASLt selections: the own NT form (datr_amd.gemm.BACKEND)
+            y2 = gemm.gemm_nt(x2, w2, shift=None if bias is None else bias.contiguous(), relu=bool(relu))
+        elif relu:
             y2 = torch._addmm_activation(bias, x2, w2.t(), use_gelu=False)
         elif bias is not None:
             y2 = torch.addmm(bias, x2, w2.t())
@@ -78,7 +81,8 @@ class _Conv1x1(Function):
         dz2 = dz.permute(0, 2, 3, 1).reshape(-1, co)
         dx = dw = db = None
         if need[0]:
-            dx = dz2.mm(w2).view(N, H, W, C).permute(0, 3, 1, 2)
+            from . import gemm
+            dx = (gemm.gemm_nn(dz2, w2) if gemm.own_big(dz2, w2) else dz2.mm(w2)).view(N, H, W, C).permute(0, 3, 1, 2)
         if need[1]:
             x2 = x.permute(0, 2, 3, 1).reshape(-1, C)
             if N * H * W <= WGRAD_GEMM_MAX_PIXELS:

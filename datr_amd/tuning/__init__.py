@@ -13,6 +13,9 @@ keep the library default.  Numerics are unchanged: every candidate is a plain fp
 
 Convolutions
 ------------
+(Since round 4 no MIOpen kernel is left in the training step -- every convolution runs on own kernels -- so
+the find-db below is only loaded on request, DATR_MIOPEN_DB=1: it matters for the A/B switches that send
+convolutions back to the library, DATR_OWN_CONV3X3=0 / DATR_OWN_CONV_S2=0 / --no-channels-last.)
 PyTorch calls MIOpen in "immediate" mode (`torch.backends.cudnn.benchmark = False`): for a
 problem MIOpen has never measured it falls back to a heuristic solver choice.  `miopen/` holds
 MIOpen's own user find-db / perf-db text files after exhaustive Find runs of bench.py's
@@ -51,13 +54,34 @@ def enable_miopen_db(src: str = MIOPEN_DB) -> bool:
     except OSError:
         return False
     os.environ["MIOPEN_USER_DB_PATH"] = dst
+    import atexit
+    atexit.register(shutil.rmtree, dst, True)        # the per-process copy does not outlive the process
     return True
 
 
-def enable(path: str = RESULTS, tune: bool = False) -> bool:
-    """Turn TunableOp on with the shipped selections.  Returns False (and leaves everything at
-    the library defaults) when the file is missing or this build has no TunableOp."""
-    if torch.cuda.is_available():
+def enable(path: str = None, tune: bool = False) -> bool:
+    """Turn TunableOp on with the shipped selections.  Returns False when the file is missing, does not
+    validate against the installed torch / hipBLASLt, or this build has no TunableOp -- and then (unless
+    DATR_GEMM_BACKEND=library) routes the large linear / FFN / 1x1-convolution products to the own GEMM family
+    (datr_amd.gemm.set_backend("own")): hipBLASLt's default heuristic would run the FFN shapes at ~83 TF/s
+    where the selections and the own kernels both reach ~130."""
+    from .. import gemm
+    forced = os.environ.get("DATR_GEMM_BACKEND", "auto")
+    if path is None:
+        path = os.environ.get("DATR_TUNING_FILE") or RESULTS
+    ok = _enable(path, tune)
+    if forced == "own":
+        gemm.set_backend("own", "DATR_GEMM_BACKEND=own")
+    elif forced == "library" or ok:
+        gemm.set_backend("library", "hipBLASLt, per-shape selections of datr_amd/tuning" if ok
+                         else "DATR_GEMM_BACKEND=library: hipBLASLt default heuristic")
+    else:
+        gemm.set_backend("own", "tuning file missing or not valid for this torch / hipBLASLt: own GEMM family")
+    return ok
+
+
+def _enable(path: str, tune: bool) -> bool:
+    if torch.cuda.is_available() and os.environ.get("DATR_MIOPEN_DB", "0") == "1":
         enable_miopen_db()
     if not torch.cuda.is_available() or not hasattr(torch.cuda, "tunable"):
         return False

@@ -28,7 +28,11 @@ extern "C" {
 #define DATR_ELAUNCH      -3   /* hipGetLastError() != hipSuccess after the launch           */
 
 const char *datr_strerror(int code);
-/* ABI version: bumped whenever a signature in this header changes. */
+/* ABI version: bumped whenever an exported signature, a struct or a memory layout of this header changes.
+ * 2 (round 5): round 4 had removed datr_conv3x3_forward_f32 / datr_conv3x3_nhwc_forward_f32 /
+ *   datr_gemm_k256_f32 / datr_wgrad_k256_f32, changed the Winograd filter layout to [16][Cin/8][Cout][8] and
+ *   added datr_gemm_epilogue / datr_adamw_tensor without a bump; datr_adamw_tensor.used_index < 0 now means
+ *   "no used flag: always update". */
 int datr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------

@@ -143,3 +143,33 @@ def test_split_bf16_inner_product_is_fp32_grade(M, N, K, monkeypatch):
     split = errors()
     for e, s_ in zip(exact, split):
         assert e < 1e-6 and s_ < 1e-6 and s_ < 2 * e + 1e-7, (exact, split)
+
+
+def test_nan_travels_through_relu_and_gate_epilogues():
+    """A NaN accumulator must come out NaN -- as through torch.relu / addmm (forward) and through
+    threshold_backward under a NaN gate (backward) -- so that the loss guard of the training loop
+    (/root/reference/engine.py:81-84) sees a diverged run; fmaxf / `gate > 0` would have returned 0."""
+    from datr_amd import gemm
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(300, 64, generator=g).to(dev)
+    w = torch.randn(96, 64, generator=g).to(dev)
+    shift = torch.randn(96, generator=g).to(dev)
+    x[7, 3] = float("nan")
+    y = gemm.gemm_nt(x, w, shift=shift, relu=True)
+    ref = torch.relu(x @ w.t() + shift)
+    assert torch.isnan(y[7]).all() and torch.isnan(ref[7]).all()
+    assert not torch.isnan(y[torch.arange(300, device=dev) != 7]).any()
+    y2 = gemm.gemm_nt(x, w, shift=shift, relu=False)
+    assert torch.isnan(y2[7]).all() and not torch.isinf(y2).any()
+    # data gradient with a gate: dz = (dy @ w) * [h > 0] in torch's threshold_backward semantics (h <= 0 ? 0 : dz)
+    dy = torch.randn(300, 96, generator=g).to(dev)
+    h = torch.randn(300, 64, generator=g).to(dev)
+    h[11, 5] = float("nan")
+    dz = gemm.gemm_nn(dy, w, gate=h)
+    ref = torch.where(h <= 0, torch.zeros((), device=dev), dy @ w)
+    torch.testing.assert_close(dz, ref, rtol=1e-4, atol=1e-4, equal_nan=True)
+    assert dz[11, 5] != 0 and not torch.isnan(dz[11, 5])     # the gradient passes a NaN gate (h <= 0 is false)
+    dy[20, 0] = float("nan")
+    dz = gemm.gemm_nn(dy, w, gate=h.abs() + 1.0)
+    assert torch.isnan(dz[20]).all()
