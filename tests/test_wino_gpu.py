@@ -181,7 +181,7 @@ def test_wide_bottleneck_weight_gradient_in_the_winograd_domain(monkeypatch):
         monkeypatch.setattr(backbone, "_CAPTURE", None)
         assert len(calls) == 1                       # the own weight gradient ran in the first pass only
         yr, ref = reference(acts[0])
-        torch.testing.assert_close(y.detach().double(), yr.detach(), rtol=1e-4, atol=1e-5 * float(yr.abs().max()))
+        torch.testing.assert_close(y.detach().double(), yr.detach(), rtol=1e-4, atol=1e-5 * float(yr.detach().abs().max()))
         for a, b in zip(got, ref):
             torch.testing.assert_close(a.double(), b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
 
