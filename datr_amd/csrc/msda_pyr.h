@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 
-constexpr int kPyrMaxR = 16;                     // regions per axis
+#ifndef PYR_MAXR
+#define PYR_MAXR 16
+#endif
+constexpr int kPyrMaxR = PYR_MAXR;               // regions per axis
 
 struct PyrMeta {
     int H[4], W[4], start[4];
