@@ -706,11 +706,24 @@ def linear_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> to
     return torch.relu(torch.nn.functional.linear(x, weight, bias))
 
 
+NOGRAD_OWN_MIN_ROWS = int(os.environ.get("DATR_NOGRAD_LINEAR_OWN_MIN_ROWS", "16384"))
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """F.linear; device float32 inputs with a bias of a multiple of 4 features take _LinearFn."""
     if x.is_cuda and x.dtype == torch.float32 and bias is not None and weight.shape[0] % 4 == 0 \
             and x.dim() >= 2 and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
         return _LinearFn.apply(x, weight, bias)
+    if x.is_cuda and x.dtype == torch.float32 and bias is not None and x.dim() >= 2 and x.is_contiguous() \
+            and weight.is_contiguous() and x.shape[-1] % 32 == 0 and weight.shape[0] % 4 == 0 \
+            and x.numel() // x.shape[-1] >= NOGRAD_OWN_MIN_ROWS and not torch.is_autocast_enabled() \
+            and x.data_ptr() % 16 == 0:
+        # without autograd (the two-stage pass over all 88 892 encoder tokens, deformable_transformer.py:329-336):
+        # F.linear on a 3-d input is hipBLASLt's bias-epilogue entry, whose pick for [88 892, 256] x [256, 256] ran
+        # 639 us in the round-4 step (profiles/r04_library_gemm_calls.txt) where the own NT form runs 111 us
+        from . import gemm
+        y = gemm.gemm_nt(x.reshape(-1, x.shape[-1]), weight, shift=bias.contiguous())
+        return y.view(*x.shape[:-1], weight.shape[0])
     return torch.nn.functional.linear(x, weight, bias)
 
 

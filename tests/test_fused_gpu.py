@@ -146,7 +146,14 @@ def test_fast_linear_matches_autograd(rows, cin, cout):
     scale = max(float(ref[3].abs().max()), 1e-6)
     assert float((got[3] - ref[3]).abs().max()) <= 2e-5 * scale
     with torch.no_grad():
-        assert torch.equal(lin(x), yr.detach())
+        # without autograd the library call from 16 384 rows on is the own NT form (fused.linear): same product,
+        # another fp32 summation order
+        yn = lin(x)
+        if 2 * rows >= 16384:
+            exact = torch.nn.functional.linear(x.detach().double(), lin.weight.double(), lin.bias.double())
+            assert float((yn.double() - exact).abs().max()) <= 4e-6 * float(exact.abs().max())
+        else:
+            assert torch.equal(yn, yr.detach())
 
 
 def test_fast_linear_takes_own_weight_gradient_kernel_and_matches_autograd():
