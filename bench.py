@@ -40,8 +40,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
-PMC_RECORD = "r04_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
-STEP_MFMA_RECORD = "r04_step_mfma.txt"   # in-step matrix-pipe busy per kernel family (committed PMC pass)
+PMC_RECORD = "r05_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
+STEP_MFMA_RECORD = "r05_step_mfma.txt"   # in-step matrix-pipe busy per kernel family (committed PMC pass)
 
 
 from datr_amd.training import build_training, run_steps, synthetic_batch  # noqa: E402

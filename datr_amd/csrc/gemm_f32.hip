@@ -52,7 +52,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // EXPERIMENTAL inner product (template parameter SP = 6, off by default: DATR_GEMM_SPLIT_BF16=1): the fp32
 // operands are split EXACTLY into three bf16 pieces each -- a = hi + mid + lo, 24 mantissa bits = 3 x 8, every
 // residual a - bf16(a) is exact in fp32 -- and the six largest of the nine piece products are accumulated in
-// fp32 by v_mfma_f32_32x32x16_bf16 (the three dropped ones are below 2^-32 of the product; measured error against
+// fp32 by v_mfma_f32_32x32x16_bf16 (of the three dropped ones mid x lo and lo x mid are ~2^-26..2^-24 of the product, lo x lo ~2^-32; measured error against
 // float64 is BELOW the fp32 MFMA chain's, tools/probes/split_bf16/).  The bf16 pipe does 16x the multiply-adds
 // per cycle of v_mfma_f32_32x32x2_f32: six products leave 2.67x the fp32 rate if the split's ~5.5 VALU
 // operations per element stay out of the way.
