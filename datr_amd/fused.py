@@ -717,10 +717,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.T
     if x.is_cuda and x.dtype == torch.float32 and bias is not None and x.dim() >= 2 and x.is_contiguous() \
             and weight.is_contiguous() and x.shape[-1] % 32 == 0 and weight.shape[0] % 4 == 0 \
             and x.numel() // x.shape[-1] >= NOGRAD_OWN_MIN_ROWS and not torch.is_autocast_enabled() \
-            and x.data_ptr() % 16 == 0:
+            and x.data_ptr() % 16 == 0 and x.shape[-1] <= 512:
         # without autograd (the two-stage pass over all 88 892 encoder tokens, deformable_transformer.py:329-336):
         # F.linear on a 3-d input is hipBLASLt's bias-epilogue entry, whose pick for [88 892, 256] x [256, 256] ran
-        # 639 us in the round-4 step (profiles/r04_library_gemm_calls.txt) where the own NT form runs 111 us
+        # 639 us in the round-4 step (profiles/r04_library_gemm_calls.txt) where the own NT form runs 111 us.  Short
+        # reductions only (tools/probes/nograd_linear_probe.py: K = 256 own 127 / 167 us against 131 / 185 us for
+        # N = 256 / 384, a tie at N = 2048; K = 2048 the library's 668 us against 749 us -- the eval / teacher FFN)
         from . import gemm
         y = gemm.gemm_nt(x.reshape(-1, x.shape[-1]), weight, shift=bias.contiguous())
         return y.view(*x.shape[:-1], weight.shape[0])
