@@ -69,6 +69,9 @@ namespace {
 #ifndef PYRB_INFLIGHT
 #define PYRB_INFLIGHT 8
 #endif
+#ifndef PYRB_WAVES_PER_SIMD
+#define PYRB_WAVES_PER_SIMD 1      // minimum 256-thread workgroups per CU the register allocation must allow (development)
+#endif
 #ifndef PYRB_BANDS
 #define PYRB_BANDS 0
 #endif
@@ -152,7 +155,7 @@ struct Sample {
 // kDots = false: grad_loc / grad_attn come from msda_fwd_pyr2.hip's LDS-window kernel
 // (msda_bwd_dots_pyr2_d32); this kernel then reads no value rows at all.
 template <class C, bool kDots>
-__global__ __launch_bounds__(C::kThreads) void msda_bwd_pyr_d32(
+__global__ __launch_bounds__(C::kThreads, PYRB_WAVES_PER_SIMD * C::kThreads / 256 > 0 ? PYRB_WAVES_PER_SIMD * C::kThreads / 256 : 1) void msda_bwd_pyr_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const float *__restrict__ loc, const float *__restrict__ attn, const PyrMeta pm, int S, int M,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
