@@ -106,15 +106,18 @@ __global__ __launch_bounds__(kThreads) void ln_class_max_kernel(
     }
 }
 
+// NS = 2: partial sums of d gamma, d beta.  NS = 3: also the column sums of dx -- when the normalised tensor is
+// x + linear(h), they are that linear layer's bias gradient (the FFN sub-block's db2: no separate pass over dx).
+template <int NS>
 __global__ __launch_bounds__(kBwdThreads) void add_ln_bwd_kernel(
     const float4 *__restrict__ dy, const float4 *__restrict__ x, const float4 *__restrict__ res,
     const float *__restrict__ mean, const float *__restrict__ rstd, const float4 *__restrict__ gamma,
-    int64_t rows, float4 *__restrict__ dx, float4 *__restrict__ partial /* [grid][2][64] float4 */)
+    int64_t rows, float4 *__restrict__ dx, float4 *__restrict__ partial /* [grid][NS][64] float4 */)
 {
-    __shared__ float4 red[kBwdWaves][2][64];
+    __shared__ float4 red[kBwdWaves][NS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 g = gamma[lane];
-    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg, ds = dg;
     for (int64_t r = (int64_t)blockIdx.x * kBwdWaves + wave; r < rows; r += (int64_t)gridDim.x * kBwdWaves) {
         float4 s = x[r * 64 + lane];
         if (res) {
@@ -133,28 +136,31 @@ __global__ __launch_bounds__(kBwdThreads) void add_ln_bwd_kernel(
         dx[r * 64 + lane] = o;
         dg.x += d.x * xh.x; dg.y += d.y * xh.y; dg.z += d.z * xh.z; dg.w += d.w * xh.w;
         db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
+        if (NS == 3) { ds.x += o.x; ds.y += o.y; ds.z += o.z; ds.w += o.w; }
     }
     red[wave][0][lane] = dg;
     red[wave][1][lane] = db;
+    if (NS == 3) red[wave][2][lane] = ds;
     __syncthreads();
-    if (wave < 2) {                               // wave 0 folds d gamma, wave 1 d beta
+    if (wave < NS) {                              // wave 0 folds d gamma, wave 1 d beta, wave 2 the sums of dx
         float4 t = red[0][wave][lane];
         for (int w = 1; w < kBwdWaves; ++w) {
             const float4 u = red[w][wave][lane];
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        partial[((int64_t)blockIdx.x * 2 + wave) * 64 + lane] = t;
+        partial[((int64_t)blockIdx.x * NS + wave) * 64 + lane] = t;
     }
 }
 
 // partial [nblk][2][64] float4 -> dgamma [64] float4, dbeta [64] float4.  One workgroup per output,
 // 16 waves share the partial rows (unrolled independent loads), then meet in LDS.
 __global__ __launch_bounds__(kFinThreads) void add_ln_finish_kernel(
-    const float4 *__restrict__ partial, int nblk, float4 *__restrict__ dgamma, float4 *__restrict__ dbeta)
+    const float4 *__restrict__ partial, int nblk, int ns, float4 *__restrict__ dgamma, float4 *__restrict__ dbeta,
+    float4 *__restrict__ dxsum)
 {
     __shared__ float4 red[kFinWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int which = blockIdx.x;                 // 0 = gamma, 1 = beta
+    const int which = blockIdx.x;                 // 0 = gamma, 1 = beta, 2 = column sums of dx
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     // 8 independent loads in flight per wave, summed in a fixed order
     for (int b0 = wave; b0 < nblk; b0 += kFinWaves * 8) {
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(kFinThreads) void add_ln_finish_kernel(
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int b = b0 + u * kFinWaves;
-            v[u] = b < nblk ? partial[((int64_t)b * 2 + which) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u] = b < nblk ? partial[((int64_t)b * ns + which) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(kFinThreads) void add_ln_finish_kernel(
     if (wave == 0) {
         float4 t = red[0][lane];
         for (int w = 1; w < kFinWaves; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
-        (which ? dbeta : dgamma)[lane] = t;
+        (which == 0 ? dgamma : which == 1 ? dbeta : dxsum)[lane] = t;
     }
 }
 
@@ -189,7 +195,7 @@ int bwd_grid_for(int64_t rows) {
 }  // namespace
 
 extern "C" int64_t datr_add_layernorm_partial_floats(int64_t rows) {
-    return (int64_t)bwd_grid_for(rows) * 2 * kC;
+    return (int64_t)bwd_grid_for(rows) * 3 * kC;
 }
 
 extern "C" int datr_add_layernorm_forward_f32(const float *x, const float *res, const float *gamma,
@@ -220,28 +226,55 @@ extern "C" int datr_layernorm_class_max_f32(const float *x, const float *gamma, 
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
 }
 
-extern "C" int datr_add_layernorm_backward_f32(const float *dy, const float *x, const float *res,
-                                               const float *mean, const float *rstd,
-                                               const float *gamma, int64_t rows, int64_t C, float *dx,
-                                               float *partial, float *dgamma, float *dbeta,
-                                               void *stream) {
+static int add_layernorm_backward(const float *dy, const float *x, const float *res, const float *mean,
+                                  const float *rstd, const float *gamma, int64_t rows, int64_t C, float *dx,
+                                  float *partial, float *dgamma, float *dbeta, float *dxsum, void *stream) {
     if (rows < 0 || C != kC) return C != kC ? DATR_EUNSUPPORTED : DATR_EINVAL;
     if (!dgamma || !dbeta) return DATR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) {
-        if (hipMemsetAsync(dgamma, 0, kC * 4, st) != hipSuccess || hipMemsetAsync(dbeta, 0, kC * 4, st) != hipSuccess)
+        if (hipMemsetAsync(dgamma, 0, kC * 4, st) != hipSuccess || hipMemsetAsync(dbeta, 0, kC * 4, st) != hipSuccess ||
+            (dxsum && hipMemsetAsync(dxsum, 0, kC * 4, st) != hipSuccess))
             return DATR_ELAUNCH;
         return DATR_OK;
     }
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !partial) return DATR_EINVAL;
     const int nblk = bwd_grid_for(rows);
-    hipLaunchKernelGGL(add_ln_bwd_kernel, dim3((unsigned)nblk), dim3(kBwdThreads), 0, st,
-                       reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x),
-                       reinterpret_cast<const float4 *>(res), mean, rstd,
-                       reinterpret_cast<const float4 *>(gamma), rows, reinterpret_cast<float4 *>(dx),
-                       reinterpret_cast<float4 *>(partial));
-    hipLaunchKernelGGL(add_ln_finish_kernel, dim3(2), dim3(kFinThreads), 0, st,
-                       reinterpret_cast<const float4 *>(partial), nblk,
-                       reinterpret_cast<float4 *>(dgamma), reinterpret_cast<float4 *>(dbeta));
+    const int ns = dxsum ? 3 : 2;
+    if (dxsum)
+        hipLaunchKernelGGL(add_ln_bwd_kernel<3>, dim3((unsigned)nblk), dim3(kBwdThreads), 0, st,
+                           reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x),
+                           reinterpret_cast<const float4 *>(res), mean, rstd,
+                           reinterpret_cast<const float4 *>(gamma), rows, reinterpret_cast<float4 *>(dx),
+                           reinterpret_cast<float4 *>(partial));
+    else
+        hipLaunchKernelGGL(add_ln_bwd_kernel<2>, dim3((unsigned)nblk), dim3(kBwdThreads), 0, st,
+                           reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x),
+                           reinterpret_cast<const float4 *>(res), mean, rstd,
+                           reinterpret_cast<const float4 *>(gamma), rows, reinterpret_cast<float4 *>(dx),
+                           reinterpret_cast<float4 *>(partial));
+    hipLaunchKernelGGL(add_ln_finish_kernel, dim3((unsigned)ns), dim3(kFinThreads), 0, st,
+                       reinterpret_cast<const float4 *>(partial), nblk, ns,
+                       reinterpret_cast<float4 *>(dgamma), reinterpret_cast<float4 *>(dbeta),
+                       reinterpret_cast<float4 *>(dxsum));
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+extern "C" int datr_add_layernorm_backward_f32(const float *dy, const float *x, const float *res,
+                                               const float *mean, const float *rstd,
+                                               const float *gamma, int64_t rows, int64_t C, float *dx,
+                                               float *partial, float *dgamma, float *dbeta,
+                                               void *stream) {
+    return add_layernorm_backward(dy, x, res, mean, rstd, gamma, rows, C, dx, partial, dgamma, dbeta, nullptr, stream);
+}
+
+// The same, and dxsum[c] = sum over rows of dx[r][c] (deterministic: fixed-order partial sums): when the normalised
+// tensor is x + linear(h) this is that linear layer's bias gradient.
+extern "C" int datr_add_layernorm_backward_colsum_f32(const float *dy, const float *x, const float *res,
+                                                      const float *mean, const float *rstd,
+                                                      const float *gamma, int64_t rows, int64_t C, float *dx,
+                                                      float *partial, float *dgamma, float *dbeta, float *dxsum,
+                                                      void *stream) {
+    if (!dxsum) return DATR_EINVAL;
+    return add_layernorm_backward(dy, x, res, mean, rstd, gamma, rows, C, dx, partial, dgamma, dbeta, dxsum, stream);
 }

@@ -383,16 +383,20 @@ class _FFNAddNorm(Function):
         dsum = torch.empty_like(x2)                       # gradient of (x + ffn(x)): both addends get it
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(gamma)
+        db2 = torch.empty_like(gamma)                     # linear2's bias gradient = the column sums of dsum
         partial = torch.empty(int(_native.lib.datr_add_layernorm_partial_floats(rows)),
                               device=x2.device, dtype=torch.float32)
         stream = _native.current_stream_ptr(x2.device)
         with torch.cuda.device(x2.device):
-            rc = _native.lib.datr_add_layernorm_backward_f32(
+            # ... which fall out of the LayerNorm backward's own pass over dsum (no column-sum launches)
+            rc = _native.lib.datr_add_layernorm_backward_colsum_f32(
                 d2.data_ptr(), y.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                rows, C, dsum.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream)
+                rows, C, dsum.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), db2.data_ptr(), stream)
         _native.check(rc, "add_layernorm_backward")
         need = ctx.needs_input_grad
-        dw2, db2 = _ffn_wgrad(dsum, h, need[3], need[4])
+        dw2 = _ffn_wgrad(dsum, h, need[3], False)[0]
+        if not need[4]:
+            db2 = None
         dh, db1 = _ffn_hidden_gradient(dsum, w2, h)
         dw1 = _ffn_wgrad(dh, x2, need[1], False)[0]
         dx = _dgrad(dh, w1, residual=dsum).view(ctx.shape) if need[0] else None

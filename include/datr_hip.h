@@ -699,6 +699,12 @@ int datr_add_layernorm_backward_f32(const float *dy, const float *x, const float
                                     const float *mean, const float *rstd, const float *gamma,
                                     int64_t rows, int64_t C, float *dx, float *partial, float *dgamma,
                                     float *dbeta, void *stream);
+/* The same, plus dxsum[C] = column sums of dx (fixed-order partial sums): when the normalised tensor is
+ * x + linear(h) -- the FFN sub-block of deformable_transformer.py:803-806 -- this is linear's bias gradient. */
+int datr_add_layernorm_backward_colsum_f32(const float *dy, const float *x, const float *res,
+                                    const float *mean, const float *rstd, const float *gamma,
+                                    int64_t rows, int64_t C, float *dx, float *partial, float *dgamma,
+                                    float *dbeta, float *dxsum, void *stream);
 
 /* score[r] = max_c (LayerNorm(x[r]) . w[c] + bias[c]): the class score the two-stage query selection ranks the
  * encoder tokens by (/root/reference/models/dino/deformable_transformer.py:335-342: enc_output_norm, the class head,
