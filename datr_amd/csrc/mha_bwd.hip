@@ -93,7 +93,9 @@ __device__ __forceinline__ void load16(const float *p, float scale, float (&r)[1
 // ------------------------------------------------------------------------------------------------
 // dQ (and D): a workgroup owns 32 queries of one (batch, head); wave w walks key tiles w, w + 4, ...
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void mha_bwd_dq_d32(
+// (three waves per SIMD: 156 registers without a spill; 1 120 workgroups then run in two rounds of 768 slots instead of
+// three of 512: 115 -> 103 us per layer at N = 4)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void mha_bwd_dq_d32(
     const float *__restrict__ gout, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const float *__restrict__ out, const float *__restrict__ lse,
     const float *__restrict__ mask, float *__restrict__ delta, float *__restrict__ dq, int L, int H,
@@ -201,13 +203,16 @@ __global__ __launch_bounds__(kThreads) void mha_bwd_dq_d32(
 // ------------------------------------------------------------------------------------------------
 // dK, dV: a workgroup owns 32 keys of one (batch, head); wave w walks query tiles w, w + 4, ...
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void mha_bwd_dkv_d32(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void mha_bwd_dkv_d32(
     const float *__restrict__ gout, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const float *__restrict__ lse, const float *__restrict__ delta,
     const float *__restrict__ mask, float *__restrict__ dk, float *__restrict__ dv, int L, int H,
     BwdStrides st, float scale)
 {
-    __shared__ __attribute__((aligned(16))) float smem[kWaves * kWaveLds];
+    // + the workgroup's own K^T (pre-scaled) and V^T tiles: every wave multiplies by the same 32 keys, so they sit in LDS
+    // once and a wave re-reads its 2 x 16 operand registers per query tile (8 ds_read_b128) instead of holding them
+    // through the softmax and the second pair of products -- the 32 registers that let three waves per SIMD fit
+    __shared__ __attribute__((aligned(16))) float smem[kWaves * kWaveLds + 2 * 32 * TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int n = blockIdx.y / H, h = blockIdx.y % H;
@@ -219,9 +224,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const float *db = delta + ((long)n * H + h) * L;
     float *Qs = smem + wave * kWaveLds, *Gs = Qs + 32 * TS, *Ls = Gs + 32 * TS, *Ds = Ls + 32;
 
-    float kreg[16], vreg[16];
-    load16(k + (long)kc * st.k_l + (long)n * st.k_n + h * 32 + lhi * 16, scale, kreg);
-    load16(v + (long)kc * st.v_l + (long)n * st.v_n + h * 32 + lhi * 16, 1.f, vreg);
+    float *Kt = smem + kWaves * kWaveLds, *Vt = Kt + 32 * TS;
+    if (wave == 0) {
+        float kreg0[16], vreg0[16];
+        load16(k + (long)kc * st.k_l + (long)n * st.k_n + h * 32 + lhi * 16, scale, kreg0);
+        load16(v + (long)kc * st.v_l + (long)n * st.v_n + h * 32 + lhi * 16, 1.f, vreg0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4 *>(&Kt[l31 * TS + lhi * 16 + 4 * i]) = make_float4(kreg0[4 * i], kreg0[4 * i + 1], kreg0[4 * i + 2], kreg0[4 * i + 3]);
+            *reinterpret_cast<float4 *>(&Vt[l31 * TS + lhi * 16 + 4 * i]) = make_float4(vreg0[4 * i], vreg0[4 * i + 1], vreg0[4 * i + 2], vreg0[4 * i + 3]);
+        }
+    }
+    __syncthreads();
 
     f32x16 dkacc, dvacc;
 #pragma unroll
@@ -233,23 +247,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     float ln = 0.f, dn = 0.f;
     const int step = 32 * kWaves;
     int i0 = wave * 32;
-    if (i0 < L) {
+    for (; i0 < L; i0 += step) {
         fetch2(qb, gb, st.q_l, st.g_l, i0 + srow, shalf, L, qn, gn);
         if (lane < 32) { ln = lb[min(i0 + lane, L - 1)]; dn = db[min(i0 + lane, L - 1)]; }
-    }
-    for (; i0 < L; i0 += step) {
         stage2(Qs, Gs, srow, shalf, qn, gn);
         if (lane < 32) { Ls[lane] = ln; Ds[lane] = dn; }
-        if (i0 + step < L) {
-            fetch2(qb, gb, st.q_l, st.g_l, i0 + step + srow, shalf, L, qn, gn);
-            if (lane < 32) { ln = lb[min(i0 + step + lane, L - 1)]; dn = db[min(i0 + step + lane, L - 1)]; }
-        }
 
         // S = Q K^T and dP = dO V^T : [32 queries] x [32 keys]
         f32x16 sacc, pacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
-        mm2_rows(Qs, Gs, l31, lhi, kreg, vreg, sacc, pacc);
+        {
+            float kreg[16], vreg[16];
+            load16(&Kt[l31 * TS + lhi * 16], 1.f, kreg);
+            load16(&Vt[l31 * TS + lhi * 16], 1.f, vreg);
+            mm2_rows(Qs, Gs, l31, lhi, kreg, vreg, sacc, pacc);
+        }
 
         // lane = key; register e = query (e&3) + 8 (e>>2) + 4 lhi
         float p[16], ds[16];
