@@ -542,6 +542,15 @@ Plan pick_plan(int form, long M, long N, long K)
     } else {
         if (N <= 64) { p.tm = 2; p.tn = 1; p.bk = 32; }        // one column tile: tall tiles, full 128-B k-rows
         else if (tiles(p) < 1024) p.tn = 1;
+        else {
+            // Round quantisation: 64 x 128 tiles run four workgroups per CU = 1 024 slots.  A launch of 2 104 tiles (the
+            // 16 800-pixel maps x 1 024 channels) pays a third round for 5 % of its tiles; as 64 x 64 tiles (five per CU,
+            // 1 280 slots, 4 208 tiles) it makes 3.3 rounds of half-size tiles: 86 against 102 us (profiles/
+            // r04_gemm_sweep.txt, l3.conv3 nn).  Only for a few rounds: beyond, the larger tile's efficiency wins.
+            static const bool rounds_rule = !(getenv("DATR_GEMM_ROUNDS_RULE") && atoi(getenv("DATR_GEMM_ROUNDS_RULE")) == 0);
+            const double r = (double)tiles(p) / 1024.0, frac = r - (double)(long)r;
+            if (rounds_rule && r < 3.5 && frac > 0.0 && frac <= 0.4) p.tn = 1;
+        }
     }
     if (p.split) {
         // the split costs VALU per FRAGMENT, the products pay per fragment PAIR: 128 x 128 tiles (two fragments
