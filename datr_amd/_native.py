@@ -40,6 +40,8 @@ _SIGNATURES = {
     "datr_add_layernorm_forward_f32": [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp],
     "datr_add_layernorm_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "datr_add_layernorm_backward_colsum_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "datr_add_layernorm_forward_query_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
+    "datr_add_layernorm_backward_fanin_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "datr_normalize_pad_u8_f32": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, ctypes.c_int, _vp, _vp, _vp],
     "datr_lsap_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "datr_colsum_f32": [_vp, _i64, _i64, _vp, _vp, _vp],

@@ -44,12 +44,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(
     const float4 *__restrict__ x, const float4 *__restrict__ res, const float4 *__restrict__ gamma,
     const float4 *__restrict__ beta, int64_t rows, float eps, float4 *__restrict__ y,
-    float *__restrict__ mean, float *__restrict__ rstd)
+    float *__restrict__ mean, float *__restrict__ rstd,
+    const float4 *__restrict__ add /* may be null */, float4 *__restrict__ y2 /* y + add */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 g = gamma[lane], b = beta[lane];
     for (int64_t r = (int64_t)blockIdx.x * kWaves + wave; r < rows; r += (int64_t)gridDim.x * kWaves) {
         float4 s = x[r * 64 + lane];
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (add) p = add[r * 64 + lane];
         if (res) {
             const float4 t = res[r * 64 + lane];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(
         o.x = dx * rs * g.x + b.x; o.y = dy * rs * g.y + b.y;
         o.z = dz * rs * g.z + b.z; o.w = dw * rs * g.w + b.w;
         y[r * 64 + lane] = o;
+        if (add) y2[r * 64 + lane] = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
     }
 }
@@ -112,7 +116,8 @@ template <int NS>
 __global__ __launch_bounds__(kBwdThreads) void add_ln_bwd_kernel(
     const float4 *__restrict__ dy, const float4 *__restrict__ x, const float4 *__restrict__ res,
     const float *__restrict__ mean, const float *__restrict__ rstd, const float4 *__restrict__ gamma,
-    int64_t rows, float4 *__restrict__ dx, float4 *__restrict__ partial /* [grid][NS][64] float4 */)
+    int64_t rows, float4 *__restrict__ dx, float4 *__restrict__ partial /* [grid][NS][64] float4 */,
+    const float4 *__restrict__ dy1 /* may be null */, const float4 *__restrict__ dy2 /* may be null */)
 {
     __shared__ float4 red[kBwdWaves][NS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -124,7 +129,15 @@ __global__ __launch_bounds__(kBwdThreads) void add_ln_bwd_kernel(
             const float4 t = res[r * 64 + lane];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
-        const float4 d = dy[r * 64 + lane];
+        float4 d = dy[r * 64 + lane];
+        if (dy1) {                                // the gradients of y's other consumers, summed on load: (dy + dy1) + dy2
+            const float4 t = dy1[r * 64 + lane];
+            d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+        }
+        if (dy2) {
+            const float4 t = dy2[r * 64 + lane];
+            d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+        }
         const float mu = mean[r], rs = rstd[r];
         const float4 xh = make_float4((s.x - mu) * rs, (s.y - mu) * rs, (s.z - mu) * rs, (s.w - mu) * rs);
         const float4 dgm = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
@@ -198,18 +211,34 @@ extern "C" int64_t datr_add_layernorm_partial_floats(int64_t rows) {
     return (int64_t)bwd_grid_for(rows) * 3 * kC;
 }
 
-extern "C" int datr_add_layernorm_forward_f32(const float *x, const float *res, const float *gamma,
-                                              const float *beta, int64_t rows, int64_t C, float eps,
-                                              float *y, float *mean, float *rstd, void *stream) {
+static int add_layernorm_forward(const float *x, const float *res, const float *gamma, const float *beta,
+                                 int64_t rows, int64_t C, float eps, float *y, float *mean, float *rstd,
+                                 const float *add, float *y2, void *stream) {
     if (rows < 0 || C != kC) return C != kC ? DATR_EUNSUPPORTED : DATR_EINVAL;
     if (rows == 0) return DATR_OK;
-    if (!x || !gamma || !beta || !y || !mean || !rstd) return DATR_EINVAL;
+    if (!x || !gamma || !beta || !y || !mean || !rstd || (add && !y2)) return DATR_EINVAL;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3((unsigned)grid_for(rows)), dim3(kThreads), 0,
                        (hipStream_t)stream, reinterpret_cast<const float4 *>(x),
                        reinterpret_cast<const float4 *>(res), reinterpret_cast<const float4 *>(gamma),
                        reinterpret_cast<const float4 *>(beta), rows, eps, reinterpret_cast<float4 *>(y),
-                       mean, rstd);
+                       mean, rstd, reinterpret_cast<const float4 *>(add), reinterpret_cast<float4 *>(y2));
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
+}
+
+extern "C" int datr_add_layernorm_forward_f32(const float *x, const float *res, const float *gamma,
+                                              const float *beta, int64_t rows, int64_t C, float eps,
+                                              float *y, float *mean, float *rstd, void *stream) {
+    return add_layernorm_forward(x, res, gamma, beta, rows, C, eps, y, mean, rstd, nullptr, nullptr, stream);
+}
+
+// The same, and y2 = y + add in the same pass: an encoder layer's output together with the next layer's query
+// (tokens + position table, /root/reference/models/dino/deformable_transformer.py:789-798 `with_pos_embed`).
+extern "C" int datr_add_layernorm_forward_query_f32(const float *x, const float *res, const float *gamma,
+                                                    const float *beta, const float *add, int64_t rows, int64_t C,
+                                                    float eps, float *y, float *y2, float *mean, float *rstd,
+                                                    void *stream) {
+    if (!add || !y2) return DATR_EINVAL;
+    return add_layernorm_forward(x, res, gamma, beta, rows, C, eps, y, mean, rstd, add, y2, stream);
 }
 
 extern "C" int datr_layernorm_class_max_f32(const float *x, const float *gamma, const float *beta, const float *w,
@@ -228,7 +257,8 @@ extern "C" int datr_layernorm_class_max_f32(const float *x, const float *gamma, 
 
 static int add_layernorm_backward(const float *dy, const float *x, const float *res, const float *mean,
                                   const float *rstd, const float *gamma, int64_t rows, int64_t C, float *dx,
-                                  float *partial, float *dgamma, float *dbeta, float *dxsum, void *stream) {
+                                  float *partial, float *dgamma, float *dbeta, float *dxsum, void *stream,
+                                  const float *dy1 = nullptr, const float *dy2 = nullptr) {
     if (rows < 0 || C != kC) return C != kC ? DATR_EUNSUPPORTED : DATR_EINVAL;
     if (!dgamma || !dbeta) return DATR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -246,13 +276,15 @@ static int add_layernorm_backward(const float *dy, const float *x, const float *
                            reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x),
                            reinterpret_cast<const float4 *>(res), mean, rstd,
                            reinterpret_cast<const float4 *>(gamma), rows, reinterpret_cast<float4 *>(dx),
-                           reinterpret_cast<float4 *>(partial));
+                           reinterpret_cast<float4 *>(partial), reinterpret_cast<const float4 *>(dy1),
+                           reinterpret_cast<const float4 *>(dy2));
     else
         hipLaunchKernelGGL(add_ln_bwd_kernel<2>, dim3((unsigned)nblk), dim3(kBwdThreads), 0, st,
                            reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(x),
                            reinterpret_cast<const float4 *>(res), mean, rstd,
                            reinterpret_cast<const float4 *>(gamma), rows, reinterpret_cast<float4 *>(dx),
-                           reinterpret_cast<float4 *>(partial));
+                           reinterpret_cast<float4 *>(partial), reinterpret_cast<const float4 *>(dy1),
+                           reinterpret_cast<const float4 *>(dy2));
     hipLaunchKernelGGL(add_ln_finish_kernel, dim3((unsigned)ns), dim3(kFinThreads), 0, st,
                        reinterpret_cast<const float4 *>(partial), nblk, ns,
                        reinterpret_cast<float4 *>(dgamma), reinterpret_cast<float4 *>(dbeta),
@@ -277,4 +309,17 @@ extern "C" int datr_add_layernorm_backward_colsum_f32(const float *dy, const flo
                                                       void *stream) {
     if (!dxsum) return DATR_EINVAL;
     return add_layernorm_backward(dy, x, res, mean, rstd, gamma, rows, C, dx, partial, dgamma, dbeta, dxsum, stream);
+}
+
+// The same with up to three gradients of the normalised tensor, summed on load as (dy + dy1) + dy2 (dy1 / dy2 may be
+// null): the consumers of an encoder layer's output -- residual, value projection, next query -- hand their
+// gradients over without a separate sum over the token tensor.  dxsum may be null (no column sums).
+extern "C" int datr_add_layernorm_backward_fanin_f32(const float *dy, const float *dy1, const float *dy2,
+                                                     const float *x, const float *res, const float *mean,
+                                                     const float *rstd, const float *gamma, int64_t rows, int64_t C,
+                                                     float *dx, float *partial, float *dgamma, float *dbeta,
+                                                     float *dxsum, void *stream) {
+    if (!dy1 && dy2) return DATR_EINVAL;
+    return add_layernorm_backward(dy, x, res, mean, rstd, gamma, rows, C, dx, partial, dgamma, dbeta, dxsum, stream,
+                                  dy1, dy2);
 }

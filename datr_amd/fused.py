@@ -352,7 +352,7 @@ class _FFNAddNorm(Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, pos=None):
         shape = x.shape
         C = shape[-1]
         x2 = x.reshape(-1, C)
@@ -363,23 +363,50 @@ class _FFNAddNorm(Function):
         out = torch.empty_like(x2)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
-            rc = _native.lib.datr_add_layernorm_forward_f32(
-                y.data_ptr(), x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, float(eps),
-                out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _native.current_stream_ptr(x.device))
-        _native.check(rc, "add_layernorm_forward")
-        ctx.save_for_backward(x2, h, w1, w2, y, mean, rstd, gamma)
         ctx.shape = shape
-        return out.view(shape)
+        ctx.query = pos is not None
+        if pos is None:
+            with torch.cuda.device(x.device):
+                rc = _native.lib.datr_add_layernorm_forward_f32(
+                    y.data_ptr(), x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, float(eps),
+                    out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _native.current_stream_ptr(x.device))
+            _native.check(rc, "add_layernorm_forward")
+            ctx.save_for_backward(x2, h, w1, w2, y, mean, rstd, gamma)
+            return out.view(shape)
+        # the next encoder layer's three handles on the output: its query (output + position table, written by
+        # the same pass), the value projection's input and the residual; their gradients meet in backward's load
+        p2 = pos.reshape(-1, C)
+        p2 = p2 if p2.is_contiguous() else p2.contiguous()
+        outq = torch.empty_like(x2)
+        with torch.cuda.device(x.device):
+            rc = _native.lib.datr_add_layernorm_forward_query_f32(
+                y.data_ptr(), x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), p2.data_ptr(), rows, C, float(eps),
+                out.data_ptr(), outq.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _native.current_stream_ptr(x.device))
+        _native.check(rc, "add_layernorm_forward_query")
+        ctx.save_for_backward(x2, h, w1, w2, y, mean, rstd, gamma)
+        ctx.pos_shape = pos.shape
+        ctx.set_materialize_grads(False)
+        out = out.view(shape)
+        return outq.view(shape), out.view_as(out), out.view_as(out)
 
     @staticmethod
     @once_differentiable
     @_amp_bwd
-    def backward(ctx, dout):
+    def backward(ctx, dout, dv=None, dr=None):
         x2, h, w1, w2, y, mean, rstd, gamma = ctx.saved_tensors
         rows, C = x2.shape
-        d2 = dout.reshape(-1, C)
-        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        dpos = None
+        if ctx.query:
+            # (query, value, residual): the position table's gradient is the query's, as it arrives
+            if ctx.needs_input_grad[8] and dout is not None:
+                dpos = dout.reshape(ctx.pos_shape)
+            live = [g for g in (dout, dv, dr) if g is not None]
+            if not live:
+                live = [torch.zeros(ctx.shape, device=x2.device, dtype=x2.dtype)]
+        else:
+            live = [dout]
+        live = [g.reshape(-1, C) for g in live]
+        live = [g if g.is_contiguous() else g.contiguous() for g in live]
         dsum = torch.empty_like(x2)                       # gradient of (x + ffn(x)): both addends get it
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(gamma)
@@ -389,9 +416,15 @@ class _FFNAddNorm(Function):
         stream = _native.current_stream_ptr(x2.device)
         with torch.cuda.device(x2.device):
             # ... which fall out of the LayerNorm backward's own pass over dsum (no column-sum launches)
-            rc = _native.lib.datr_add_layernorm_backward_colsum_f32(
-                d2.data_ptr(), y.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                rows, C, dsum.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), db2.data_ptr(), stream)
+            if len(live) == 1:
+                rc = _native.lib.datr_add_layernorm_backward_colsum_f32(
+                    live[0].data_ptr(), y.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                    rows, C, dsum.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), db2.data_ptr(), stream)
+            else:
+                rc = _native.lib.datr_add_layernorm_backward_fanin_f32(
+                    live[0].data_ptr(), live[1].data_ptr(), live[2].data_ptr() if len(live) > 2 else 0,
+                    y.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                    rows, C, dsum.data_ptr(), partial.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), db2.data_ptr(), stream)
         _native.check(rc, "add_layernorm_backward")
         need = ctx.needs_input_grad
         dw2 = _ffn_wgrad(dsum, h, need[3], False)[0]
@@ -401,17 +434,26 @@ class _FFNAddNorm(Function):
         dw1 = _ffn_wgrad(dh, x2, need[1], False)[0]
         dx = _dgrad(dh, w1, residual=dsum).view(ctx.shape) if need[0] else None
         return (dx, dw1, db1 if need[2] else None, dw2, db2, dgamma if need[5] else None,
-                dbeta if need[6] else None, None)
+                dbeta if need[6] else None, None, dpos)
 
 
-def ffn_add_norm(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear, norm: torch.nn.LayerNorm):
+def ffn_add_norm(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear, norm: torch.nn.LayerNorm,
+                 next_pos: torch.Tensor = None):
     """norm(x + linear2(relu(linear1(x)))) as one node, or None when the fused kernels do not apply
-    (the caller then composes ffn_relu / add_layer_norm or the reference's ops)."""
+    (the caller then composes ffn_relu / add_layer_norm or the reference's ops).  With `next_pos` (the position
+    table the NEXT encoder layer adds to its query, deformable_transformer.py:789-798) the node returns that layer's
+    three handles (output + next_pos, output, output) -- query, value input, residual -- and sums their gradients
+    while it loads them, where `q = src + pos` and the three-way gradient sum each cost passes over the tokens."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and linear1.bias is not None
             and linear2.bias is not None and linear1.out_features % 4 == 0 and linear2.out_features == 256
             and norm.elementwise_affine and norm.bias is not None and tuple(norm.normalized_shape) == (256,)
             and torch.is_grad_enabled()):
         return None
+    if next_pos is not None:
+        if not (next_pos.shape == x.shape and next_pos.dtype == x.dtype and next_pos.device == x.device):
+            return None
+        return _FFNAddNorm.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight,
+                                 norm.bias, norm.eps, next_pos)
     return _FFNAddNorm.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight,
                              norm.bias, norm.eps)
 

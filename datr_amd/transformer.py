@@ -125,12 +125,21 @@ def _ffn(x, linear1, activation, dropout, linear2):
 FUSED_FFN_BLOCK = __import__("os").environ.get("DATR_FUSED_FFN_BLOCK", "1") != "0"   # A/B switch
 
 
-def _ffn_block(x, linear1, activation, dropout_a, linear2, dropout_b, norm):
+FUSED_NEXT_QUERY = __import__("os").environ.get("DATR_FUSED_NEXT_QUERY", "1") != "0"   # A/B switch
+
+
+def _ffn_block(x, linear1, activation, dropout_a, linear2, dropout_b, norm, next_pos=None):
     """norm(x + dropout_b(linear2(dropout_a(activation(linear1(x)))))): the FFN sub-block; one autograd
-    node on the device (fused.ffn_add_norm) when both fused halves apply, else their composition."""
+    node on the device (fused.ffn_add_norm) when both fused halves apply, else their composition.
+    With `next_pos` the fused node may return the NEXT encoder layer's three handles (query = output +
+    next_pos, value input, residual) as a tuple instead of the output."""
     if (FUSED_FFN_BLOCK and FUSED_FFN and FUSED_ADD_NORM and activation is F.relu and x.is_cuda
             and not (dropout_a.training and dropout_a.p > 0) and not (dropout_b.training and dropout_b.p > 0)):
         from .fused import ffn_add_norm
+        if next_pos is not None and FUSED_NEXT_QUERY and x.requires_grad:
+            out = ffn_add_norm(x, linear1, linear2, norm, next_pos=next_pos)
+            if out is not None:
+                return out
         out = ffn_add_norm(x, linear1, linear2, norm)
         if out is not None:
             return out
@@ -253,15 +262,22 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
-                key_padding_mask=None):
-        # three consumers of src (query, value projection, residual): one alias each, their gradients
-        # meet in one pass (fused.fan_out) instead of two pairwise adds over the token tensor
-        s_q, s_v, s_r = fan_out(src, 3)
-        q = s_q if pos is None else s_q + pos
+                key_padding_mask=None, next_pos=None):
+        """`src`: the tokens, or the (query, value input, residual) handles the previous layer's FFN node
+        returned (query already = tokens + pos).  `next_pos`: the position table of the next layer, when
+        there is one -- the result may then be such a triple (TransformerEncoder.forward chains them)."""
+        if isinstance(src, tuple):
+            q, s_v, s_r = src
+        else:
+            # three consumers of src (query, value projection, residual): one alias each, their gradients
+            # meet in one pass (fused.fan_out) instead of two pairwise adds over the token tensor
+            s_q, s_v, s_r = fan_out(src, 3)
+            q = s_q if pos is None else s_q + pos
         src = _add_norm(s_r, self.self_attn(q, reference_points, s_v, spatial_shapes,
                                             level_start_index, key_padding_mask),
                         self.dropout1, self.norm1)
-        return _ffn_block(src, self.linear1, self.activation, self.dropout2, self.linear2, self.dropout3, self.norm2)
+        return _ffn_block(src, self.linear1, self.activation, self.dropout2, self.linear2, self.dropout3, self.norm2,
+                          next_pos=next_pos)
 
 
 class TransformerEncoder(nn.Module):
@@ -313,9 +329,13 @@ class TransformerEncoder(nn.Module):
         # the position table feeds every layer: one alias per layer, one gradient sum
         pos_l = fan_out(pos, len(self.layers)) if (pos is not None and 2 <= len(self.layers) <= 8) else None
         for li, layer in enumerate(self.layers):
+            # the layer's last node also writes the next layer's query (tokens + its position table)
+            nxt = None
+            if pos is not None and li + 1 < len(self.layers):
+                nxt = pos if pos_l is None else pos_l[li + 1]
             output = layer(src=output, pos=pos if pos_l is None else pos_l[li], reference_points=reference_points,
                            spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                           key_padding_mask=key_padding_mask)
+                           key_padding_mask=key_padding_mask, next_pos=nxt)
         if self.norm is not None:
             output = self.norm(output)
         return output, None, None

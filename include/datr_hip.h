@@ -705,6 +705,20 @@ int datr_add_layernorm_backward_colsum_f32(const float *dy, const float *x, cons
                                     const float *mean, const float *rstd, const float *gamma,
                                     int64_t rows, int64_t C, float *dx, float *partial, float *dgamma,
                                     float *dbeta, float *dxsum, void *stream);
+/* Forward that also writes y2 = y + add in the same pass: an encoder layer's output together with the next layer's
+ * query, tokens + position table (`with_pos_embed`, deformable_transformer.py:789-798).  add, y2 [rows, C]. */
+int datr_add_layernorm_forward_query_f32(const float *x, const float *res, const float *gamma,
+                                         const float *beta, const float *add, int64_t rows, int64_t C,
+                                         float eps, float *y, float *y2, float *mean, float *rstd,
+                                         void *stream);
+/* Backward whose incoming gradient is (dy + dy1) + dy2, summed on load (dy1, dy2 may be NULL; dy2 only with dy1):
+ * the consumers of an encoder layer's output (residual, value projection, next query) hand their gradients over
+ * without a separate sum over the token tensor.  dxsum may be NULL (no column sums). */
+int datr_add_layernorm_backward_fanin_f32(const float *dy, const float *dy1, const float *dy2,
+                                          const float *x, const float *res, const float *mean,
+                                          const float *rstd, const float *gamma, int64_t rows, int64_t C,
+                                          float *dx, float *partial, float *dgamma, float *dbeta,
+                                          float *dxsum, void *stream);
 
 /* score[r] = max_c (LayerNorm(x[r]) . w[c] + bias[c]): the class score the two-stage query selection ranks the
  * encoder tokens by (/root/reference/models/dino/deformable_transformer.py:335-342: enc_output_norm, the class head,

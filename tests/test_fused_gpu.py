@@ -734,3 +734,72 @@ def test_linear_relu_matches_autograd(rows, cin, cout):
     for a, b in zip(got[1:], [x.grad, lin.weight.grad, lin.bias.grad]):
         scale = max(float(b.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= 3e-5 * scale
+
+
+@pytest.mark.parametrize("rows,live", [((2, 1111), (1, 1, 1)), ((4, 700), (1, 0, 1)), ((1, 260), (0, 1, 0))])
+def test_ffn_block_with_next_query_equals_the_separate_ops_bitwise(rows, live):
+    """fused._FFNAddNorm with `next_pos`: the node hands out the next encoder layer's (query = output + pos, value
+    input, residual) handles -- deformable_transformer.py:789-798 -- and sums their gradients as it loads them.
+    Against the plain node followed by fan_out and the ATen add: the same values bit for bit, forward and backward
+    (gradient order (query + value) + residual, as csrc/addn.hip sums), with any subset of the handles used."""
+    import torch.nn.functional as F
+    from datr_amd import transformer as T
+    from datr_amd.fused import fan_out
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows[1])
+    lin1, lin2, norm = torch.nn.Linear(256, 1024).to(dev), torch.nn.Linear(1024, 256).to(dev), torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.normal_(0, 0.1)
+    drop = torch.nn.Dropout(0.0)
+    x = torch.randn(*rows, 256, device=dev, requires_grad=True)
+    pos = torch.randn(*rows, 256, device=dev, requires_grad=True)
+    gs = [torch.randn(*rows, 256, device=dev) for _ in range(3)]
+    params = [lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm.weight, norm.bias]
+    res = {}
+    for fusedq in (True, False):
+        if fusedq:
+            q, v, r = T._ffn_block(x, lin1, F.relu, drop, lin2, drop, norm, next_pos=pos)
+            assert "FFNAddNorm" in type(q.grad_fn).__name__ and v.data_ptr() == r.data_ptr()
+        else:
+            y = T._ffn_block(x, lin1, F.relu, drop, lin2, drop, norm)
+            s_q, v, r = fan_out(y, 3)
+            q = s_q + pos
+        loss = sum((t * g).sum() for t, g, on in zip((q, v, r), gs, live) if on)
+        grads = torch.autograd.grad(loss, [x, pos] + params, allow_unused=True)
+        res[fusedq] = ((q, v, r), grads)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    assert (res[True][1][1] is None) == (not live[0])            # the position table's gradient = the query's
+
+
+def test_encoder_chain_of_next_queries_equals_layers_with_separate_adds(monkeypatch):
+    """TransformerEncoder.forward with the layers chained through the FFN node's three handles against the same
+    encoder with DATR_FUSED_NEXT_QUERY off: outputs bitwise equal, every gradient (tokens, position table,
+    parameters) equal to fp32 rounding."""
+    from datr_amd import transformer as T
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    layer = T.DeformableTransformerEncoderLayer(256, 512, 0.0, "relu", 4, 8, 4)
+    enc = T.TransformerEncoder(layer, 3, None, d_model=256).to(dev)
+    shapes = [(20, 28), (10, 14), (5, 7), (3, 4)]
+    S = sum(h * w for h, w in shapes)
+    spatial = torch.tensor(shapes, device=dev)
+    lsi = torch.cat([spatial.new_zeros(1), spatial.prod(1).cumsum(0)[:-1]])
+    src = torch.randn(2, S, 256, device=dev, requires_grad=True)
+    pos = torch.randn(2, S, 256, device=dev, requires_grad=True)
+    vr = torch.ones(2, 4, 2, device=dev)
+    go = torch.randn(2, S, 256, device=dev)
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(T, "FUSED_NEXT_QUERY", on)
+        y = enc(src, pos, spatial, lsi, vr, None, shapes_list=shapes)[0]
+        out[on] = (y, torch.autograd.grad(y, [src, pos] + list(enc.parameters()), go))
+    assert torch.equal(out[True][0], out[False][0])
+    # (the MSDA backward's float atomics make grad_value reproducible to fp32 rounding only)
+    for a, b in zip(out[True][1], out[False][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7

@@ -35,6 +35,7 @@ GROUPS = {
                                     "DATR_OWN_PROTOTYPES": "0", "DATR_FAN_OUT": "0"},
     "ffn-block-pieces": {"DATR_FUSED_FFN_BLOCK": "0", "DATR_FFN_FUSED_DZ": "0", "DATR_FFN_OWN_HIDDEN": "1",
                          "DATR_OWN_LINEAR_WGRAD": "0", "DATR_SELECTED_ROWS_BWD": "0"},
+    "no-next-query-node": {"DATR_FUSED_NEXT_QUERY": "0", "DATR_NOGRAD_LINEAR_OWN_MIN_ROWS": "1000000000"},
     "decoder-layout-and-projections": {"DATR_BATCH_FIRST_DECODER": "0", "DATR_MERGE_QPROJ": "0", "DATR_VALUE_PROJ_BATCH": "0",
                                        "DATR_OWN_ATTENTION": "0"},
     "msda-routes": {"DATR_MSDA_PYR_FWD": "0", "DATR_MSDA_PYR_BWD": "0", "DATR_MSDA_ADAPTIVE": "0"},
