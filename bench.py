@@ -91,6 +91,22 @@ class MsdaTimer:
             return self.orig_bwd(value, shapes, lsi, loc, attn, grad_out, step, **kw)
         self.msda.ms_deform_attn_backward = timed_bwd
 
+        # the module's own entry to the same two kernels (grad_loc / grad_attn leave as the query projection's
+        # gradient rows: the same bytes)
+        self.orig_bwd_q = self.msda.ms_deform_attn_backward_query_grad
+
+        def timed_bwd_q(value, shapes, lsi, loc, attn, grad_out, step, **kw):
+            if not self.enabled:
+                return self.orig_bwd_q(value, shapes, lsi, loc, attn, grad_out, step, **kw)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = self.orig_bwd_q(value, shapes, lsi, loc, attn, grad_out, step, **kw)
+            b.record()
+            if out is not None:
+                self.bwd_events.append((a, b))
+            return out
+        self.msda.ms_deform_attn_backward_query_grad = timed_bwd_q
+
     def backward_result(self):
         """The encoder calls' backward (two kernels: LDS-window dots + value-free sorted scatter, plus the
         zero-fill of grad_value): algorithmic bytes of SURVEY.md 8d over the HIP-event time of the call."""

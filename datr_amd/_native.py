@@ -29,6 +29,7 @@ _SIGNATURES = {
     "datr_msda_forward_tiled_f32": [_vp] * 7 + [_i64] * 7 + [_vp, _vp],
     "datr_msda_backward_tiled_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
     "datr_msda_backward_pyramid_f32": [_vp] * 9 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
+    "datr_msda_backward_pyramid_query_f32": [_vp] * 7 + [_i64] * 7 + [_vp, _vp, _vp],
     "datr_msda_backward_strided_f32": [_vp] * 6 + [_i64] * 7 + [_vp, _i64, _vp, _vp, _vp],
     "datr_msda_backward_query_tiled_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp, _vp, _vp],
     "datr_msda_forward_pyramid_f32": [_vp] * 8 + [_i64] * 7 + [_vp, _vp],

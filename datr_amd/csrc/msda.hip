@@ -748,6 +748,25 @@ int datr_msda_backward_pyramid_f32(const float *grad_out, const float *value, co
                                S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn, stream, true, envelope_host);
 }
 
+int datr_msda_backward_pyramid_query_f32(const float *grad_out, const float *value, const int64_t *shapes_host,
+                                         const int64_t *level_start_host, const float *envelope_host,
+                                         const float *loc, const float *attn, int64_t N, int64_t S, int64_t M,
+                                         int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                         float *grad_query, void *stream) {
+    if (!grad_out || !value || !loc || !attn || !grad_value || !grad_query || !shapes_host || !level_start_host)
+        return DATR_EINVAL;
+    if (!dims_ok(N, S, M, D, L, Lq, P)) return DATR_EINVAL;
+    if (Lq != S || D != 32 || M != 8 || L != 4 || P != 4 || N < 1) return DATR_EUNSUPPORTED;
+    // the A/B switches of the two-kernel backward this entry is a variant of
+    static const bool off = (getenv("DATR_MSDA_PYR_BWD") && atoi(getenv("DATR_MSDA_PYR_BWD")) == 0) ||
+                            (getenv("DATR_MSDA_BWD_SPLIT") && atoi(getenv("DATR_MSDA_BWD_SPLIT")) == 0);
+    if (off) return DATR_EUNSUPPORTED;
+    if (hipMemsetAsync(grad_value, 0, (size_t)(N * S * M * D) * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return DATR_ELAUNCH;
+    return datr_internal_msda_bwd_pyr_d32(grad_out, value, loc, attn, shapes_host, level_start_host, N, S, M, D, L,
+                                          Lq, P, envelope_host, grad_value, grad_query, nullptr, stream, 1);
+}
+
 int datr_msda_backward_strided_f32(const float *grad_out, const float *value, const int64_t *shapes_host,
                                    const int64_t *level_start_host, const float *loc, const float *attn,
                                    int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,

@@ -526,11 +526,6 @@ __global__ __launch_bounds__(C::kThreads, PYRB_WAVES_PER_SIMD * C::kThreads / 25
 
 }  // namespace
 
-DATR_INTERNAL int datr_internal_msda_bwd_dots_pyr2_d32(
-    const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
-    const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
-    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream);
-
 // Region plan of the backward kernel; false when the shape is not covered.
 // `envelope_host` ([8 heads][4 levels]{oy_lo, oy_hi, ox_lo, ox_hi} in pixels of the sampled level, or
 // NULL): the measured reach of the samples (datr_amd/msda.py OffsetMonitor, the forward's window
@@ -629,20 +624,37 @@ DATR_INTERNAL int datr_internal_msda_bwd_pyr_plan(const int64_t *shapes_host, co
 
 // Internal entry (msda.hip dispatches here): DATR_EUNSUPPORTED when the shape is not covered.
 // grad_value must be zero-filled by the caller.
+// query_grad != 0: `grad_loc` receives the gradient of the module's merged query projection ([N * Lq, M * 48], see
+// msda_fwd_pyr2.hip) in place of grad_loc / grad_attn; DATR_EUNSUPPORTED with nothing launched when the LDS-window
+// kernel does not cover the shape.
 DATR_INTERNAL int datr_internal_msda_bwd_pyr_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
     int64_t D, int64_t L, int64_t Lq, int64_t P, const float *envelope_host, float *grad_value,
-    float *grad_loc, float *grad_attn, void *stream)
+    float *grad_loc, float *grad_attn, void *stream, int query_grad)
 {
     PyrMeta pm;
     bool small = false;
     if (!bwd_pyr_plan(pm, shapes_host, level_start_host, N, S, M, D, L, Lq, P, envelope_host, &small)) return DATR_EUNSUPPORTED;
+    {
+#if PYRB_BANDS
+        const long blocks_ = (long)N * ((pm.nRy * pm.nRx + 7) / 8) * 8 * M;
+#else
+        const long blocks_ = (long)N * pm.nRy * pm.nRx * M;
+#endif
+        if (blocks_ <= 0 || blocks_ >= (1L << 31)) return DATR_EUNSUPPORTED;
+    }
     // grad_loc / grad_attn out of LDS windows by the forward's structure where its plan covers the shape
     // (DATR_MSDA_BWD_SPLIT=0: this kernel's own gathers, for A/B measurements)
     static const bool split = !(getenv("DATR_MSDA_BWD_SPLIT") && atoi(getenv("DATR_MSDA_BWD_SPLIT")) == 0);
     bool dots_done = false;
-    if (split) {
+    if (query_grad) {
+        const int rc = datr_internal_msda_bwd_dots_pyr2_d32(grad_out, value, loc, attn, shapes_host, level_start_host,
+                                                            envelope_host, N, S, M, D, L, Lq, P, grad_loc, nullptr,
+                                                            stream, 1);
+        if (rc != DATR_OK) return rc;
+        dots_done = true;
+    } else if (split) {
         const int rc = datr_internal_msda_bwd_dots_pyr2_d32(grad_out, value, loc, attn, shapes_host, level_start_host,
                                                             envelope_host, N, S, M, D, L, Lq, P, grad_loc, grad_attn,
                                                             stream);

@@ -309,7 +309,12 @@ __device__ __forceinline__ void combine_dots(float &pa, float &pw, float &ph, co
     ph = hw * (d[2] - d[0]) + p.lw * (d[3] - d[1]);
 }
 
-template <int kTPW, int kCfg, bool kDots>
+// kQueryGrad (backward): the results leave as the gradient of the module's merged query projection --
+// rows of M * 48 floats, [M][4 levels][4 points][2] offset gradients (= grad_loc: the division by (W_l, H_l) is folded
+// into the projection's weights, datr_amd/msda.py) then [M][16] logit gradients, the softmax backward
+// a_k (g_k - sum_j a_j g_j) of /root/reference/models/dino/ops/modules/ms_deform_attn.py:106 applied here -- in place
+// of grad_loc / grad_attn and a separate pass that turns them into that row (csrc/msda_prologue.hip).
+template <int kTPW, int kCfg, bool kDots, bool kQueryGrad = false>
 __device__ __forceinline__ void pyr2_body(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
     const Pyr2Meta &pm, int S, int M, int nimg, float *__restrict__ out,
@@ -656,6 +661,28 @@ __device__ __forceinline__ void pyr2_body(
             quad_transpose(res_a[t], j);
             quad_transpose(res_w[t], j);
             quad_transpose(res_h[t], j);
+            if constexpr (kQueryGrad) {
+                // lane j now holds LEVEL j's four points: their weights again, as one 16-B load (the gather's
+                // registers are free here; the line was read a few microseconds ago)
+                const f4 a4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(attn_rsrc, (soff[t] + 4 * j) * 4, 0, 0));
+                const float dot = quad_sum((a4.x * res_a[t][0] + a4.y * res_a[t][1]) +
+                                           (a4.z * res_a[t][2] + a4.w * res_a[t][3]));
+                res_a[t][0] = a4.x * (res_a[t][0] - dot);
+                res_a[t][1] = a4.y * (res_a[t][1] - dot);
+                res_a[t][2] = a4.z * (res_a[t][2] - dot);
+                res_a[t][3] = a4.w * (res_a[t][3] - dot);
+                if (ti * 16 + slot < nq) {
+                    const int row = soff[t] / (16 * M), mh = (soff[t] >> 4) - row * M;
+                    float *qrow = grad_loc + (size_t)row * (M * 48);
+                    f4 *gl = reinterpret_cast<f4 *>(qrow + (mh * 4 + j) * 8);
+                    __builtin_nontemporal_store(f4{res_a[t][0], res_a[t][1], res_a[t][2], res_a[t][3]},
+                                                reinterpret_cast<f4 *>(qrow + M * 32 + (mh * 4 + j) * 4));
+                    __builtin_nontemporal_store(f4{res_w[t][0], res_h[t][0], res_w[t][1], res_h[t][1]}, gl);
+                    __builtin_nontemporal_store(f4{res_w[t][2], res_h[t][2], res_w[t][3], res_h[t][3]}, gl + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one task at a time: the three-task variant has no registers to spare
+                continue;
+            }
             if (ti * 16 + slot < nq && (!(PYR2_ABLATE & 256) || res_a[t][0] == 123.456f)) {
                 const int idx = soff[t] + 4 * j;
                 f4 *gl = reinterpret_cast<f4 *>(grad_loc + (size_t)idx * 2);
@@ -719,22 +746,22 @@ void msda_fwd_pyr2_d32(
 
 // grad_loc / grad_attn of the encoder calls (the value-dependent half of the backward; grad_value is
 // msda_bwd_pyr.hip's sorted scatter, which needs no value rows)
-template <int kTPW, int kCfg>
+template <int kTPW, int kCfg, bool kQueryGrad>
 __global__ __launch_bounds__(kP2Configs[kCfg].threads, kP2Configs[kCfg].wgs_per_cu * kP2Configs[kCfg].threads / 256)
 void msda_bwd_dots_pyr2_d32(
     const float *__restrict__ grad_out, const float *__restrict__ value, const float *__restrict__ loc,
     const float *__restrict__ attn, const Pyr2Meta pm, int S, int M, int nimg,
     float *__restrict__ grad_loc, float *__restrict__ grad_attn)
 {
-    pyr2_body<kTPW, kCfg, true>(value, loc, attn, pm, S, M, nimg, nullptr, grad_out, grad_loc, grad_attn);
+    pyr2_body<kTPW, kCfg, true, kQueryGrad>(value, loc, attn, pm, S, M, nimg, nullptr, grad_out, grad_loc, grad_attn);
 }
 
-template <int kTPW, int kCfg>
+template <int kTPW, int kCfg, bool kQueryGrad = false>
 int launch_dots(const float *grad_out, const float *value, const float *loc, const float *attn,
                 const Pyr2Meta &pm, int64_t N, int64_t S, int64_t M, float *grad_loc, float *grad_attn,
                 hipStream_t stream) {
     constexpr Pyr2Config cfg = kP2Configs[kCfg];
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_dots_pyr2_d32<kTPW, kCfg>),
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_dots_pyr2_d32<kTPW, kCfg, kQueryGrad>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     p2_lds_bytes(cfg)) == hipSuccess;
     if (!attr_ok) return DATR_EUNSUPPORTED;
@@ -744,7 +771,7 @@ int launch_dots(const float *grad_out, const float *value, const float *loc, con
     const long blocks = (long)N * pm.nRy * pm.nRx * M;
 #endif
     if (blocks <= 0 || blocks >= (1L << 31)) return DATR_EUNSUPPORTED;
-    hipLaunchKernelGGL((msda_bwd_dots_pyr2_d32<kTPW, kCfg>), dim3((unsigned)blocks), dim3(cfg.threads),
+    hipLaunchKernelGGL((msda_bwd_dots_pyr2_d32<kTPW, kCfg, kQueryGrad>), dim3((unsigned)blocks), dim3(cfg.threads),
                        (size_t)p2_window_rows(cfg) * kRowBytes, stream, grad_out, value, loc, attn, pm, (int)S,
                        (int)M, (int)N, grad_loc, grad_attn);
     return hipGetLastError() == hipSuccess ? DATR_OK : DATR_ELAUNCH;
@@ -870,10 +897,12 @@ extern "C" int datr_internal_msda_fwd_pyr2_d32(
 // The value-dependent half of the encoder backward: grad_loc / grad_attn (every element written).
 // DATR_EUNSUPPORTED when the forward's plan does not cover the shape (the caller then lets
 // msda_bwd_pyr.hip compute them with its own gathers).
+// query_grad != 0: `grad_loc` is the [N * Lq, M * 48] gradient of the merged query projection instead (see
+// pyr2_body; grad_attn unused).
 DATR_INTERNAL int datr_internal_msda_bwd_dots_pyr2_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
     const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
-    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream)
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream, int query_grad)
 {
     if (D != 32 || L != 4 || P != 4 || Lq != S || M < 1 || M > kP2Heads || N < 1) return DATR_EUNSUPPORTED;
     if (N * S * M * 128 >= (1LL << 31)) return DATR_EUNSUPPORTED;
@@ -884,8 +913,14 @@ DATR_INTERNAL int datr_internal_msda_bwd_dots_pyr2_d32(
     const auto go = [&](auto cfg) -> int {
         constexpr int kCfg = decltype(cfg)::value;
         switch (pm.tpw) {
-            case 1: case 2: return launch_dots<2, kCfg>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
-            case 3: return launch_dots<3, kCfg>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
+            case 1: case 2:
+                if (query_grad)
+                    return launch_dots<2, kCfg, true>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
+                return launch_dots<2, kCfg>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
+            case 3:
+                if (query_grad)
+                    return launch_dots<3, kCfg, true>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
+                return launch_dots<3, kCfg>(grad_out, value, loc, attn, pm, N, S, M, grad_loc, grad_attn, st);
             default: return DATR_EUNSUPPORTED;
         }
     };

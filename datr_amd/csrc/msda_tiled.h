@@ -57,12 +57,13 @@ DATR_INTERNAL int datr_internal_msda_bwd_pyr_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,
     const int64_t *shapes_host, const int64_t *level_start_host, int64_t N, int64_t S, int64_t M,
     int64_t D, int64_t L, int64_t Lq, int64_t P, const float *envelope_host, float *grad_value,
-    float *grad_loc, float *grad_attn, void *stream);
+    float *grad_loc, float *grad_attn, void *stream, int query_grad = 0);
 
 DATR_INTERNAL int datr_internal_msda_bwd_dots_pyr2_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn, const int64_t *shapes_host,
     const int64_t *level_start_host, const float *envelope_host, int64_t N, int64_t S, int64_t M,
-    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream);
+    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_loc, float *grad_attn, void *stream,
+    int query_grad = 0);
 
 DATR_INTERNAL int datr_internal_msda_bwd_owner_d32(
     const float *grad_out, const float *value, const float *loc, const float *attn,

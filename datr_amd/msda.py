@@ -219,6 +219,41 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [grad_value, grad_loc, grad_attn]
 
 
+def ms_deform_attn_backward_query_grad(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                       grad_output, im2col_step: int, envelope=None):
+    """The encoder calls' backward for the MODULE: -> (grad_value, grad_query) with grad_query [N, Lq, M * 48] the
+    gradient of the merged (offsets | logits) query projection -- grad_sampling_loc and the softmax backward of
+    grad_attn_weight already in that projection's column layout (include/datr_hip.h,
+    datr_msda_backward_pyramid_query_f32) --, or None when the library does not cover the shape (the caller then runs
+    ms_deform_attn_backward and the prologue's own backward)."""
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    if not (_suffix(value) == "f32" and D == 32 and Lq == S and M == 8 and L == 4 and P == 4
+            and sampling_loc.dtype == value.dtype and attn_weight.dtype == value.dtype):
+        return None
+    for t, nme in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"),
+                   (grad_output, "grad_output")):
+        _require(t, nme)
+    shapes, lsi = _as_int64(spatial_shapes), _as_int64(level_start_index)
+    sh_host, ls_host = _host_meta(shapes, lsi)
+    env = None
+    if envelope is not None:
+        import numpy as np
+        env = np.ascontiguousarray(envelope, dtype=np.float32)
+        assert env.shape == (8, 4, 4)
+    grad_value = torch.empty_like(value)            # zero-filled by the library on the stream
+    grad_query = torch.empty((N, Lq, M * 48), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _native.lib.datr_msda_backward_pyramid_query_f32(
+            grad_output.data_ptr(), value.data_ptr(), sh_host.ctypes.data, ls_host.ctypes.data,
+            0 if env is None else env.ctypes.data, sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_query.data_ptr(),
+            _native.current_stream_ptr(value.device))
+    if rc == _EUNSUPPORTED:
+        return None
+    _native.check(rc, "ms_deform_attn_backward_query_grad")
+    return grad_value, grad_query
+
+
 class MSDeformAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -380,6 +415,32 @@ class _SplitLast(Function):
         return torch.cat([ga, gb], -1), None
 
 
+def _prologue_forward(both, ref):
+    rows = both.numel() // 384
+    loc = torch.empty(*both.shape[:-1], 8, 4, 4, 2, device=both.device, dtype=torch.float32)
+    attn = torch.empty(*both.shape[:-1], 8, 4, 4, device=both.device, dtype=torch.float32)
+    with torch.cuda.device(both.device):
+        rc = _native.lib.datr_msda_prologue_forward_f32(
+            both.data_ptr(), ref.data_ptr(), rows, ref.shape[-1], loc.data_ptr(), attn.data_ptr(),
+            _native.current_stream_ptr(both.device))
+    _native.check(rc, "msda_prologue_forward")
+    return loc, attn
+
+
+def _prologue_backward(d_loc, d_attn, attn, ref, shape):
+    d_loc = torch.zeros_like(attn).unsqueeze(-1).expand(*attn.shape, 2).contiguous() \
+        if d_loc is None else d_loc.contiguous()
+    d_attn = torch.zeros_like(attn) if d_attn is None else d_attn.contiguous()
+    d_both = torch.empty(shape, device=attn.device, dtype=torch.float32)
+    with torch.cuda.device(attn.device):
+        rc = _native.lib.datr_msda_prologue_backward_f32(
+            d_loc.data_ptr(), d_attn.data_ptr(), attn.data_ptr(), ref.data_ptr(),
+            d_both.numel() // 384, ref.shape[-1], d_both.data_ptr(),
+            _native.current_stream_ptr(attn.device))
+    _native.check(rc, "msda_prologue_backward")
+    return d_both
+
+
 class _Prologue(Function):
     """(sampling locations, attention weights) from the merged query projection in one launch
     each way (csrc/msda_prologue.hip); 8 heads x 4 levels x 4 points, reference points without
@@ -387,15 +448,8 @@ class _Prologue(Function):
 
     @staticmethod
     def forward(ctx, both, ref):
-        rows = both.numel() // 384
         both, ref = both.contiguous(), ref.contiguous()
-        loc = torch.empty(*both.shape[:-1], 8, 4, 4, 2, device=both.device, dtype=torch.float32)
-        attn = torch.empty(*both.shape[:-1], 8, 4, 4, device=both.device, dtype=torch.float32)
-        with torch.cuda.device(both.device):
-            rc = _native.lib.datr_msda_prologue_forward_f32(
-                both.data_ptr(), ref.data_ptr(), rows, ref.shape[-1], loc.data_ptr(), attn.data_ptr(),
-                _native.current_stream_ptr(both.device))
-        _native.check(rc, "msda_prologue_forward")
+        loc, attn = _prologue_forward(both, ref)
         ctx.save_for_backward(attn, ref)
         ctx.shape = both.shape
         return loc, attn
@@ -404,19 +458,54 @@ class _Prologue(Function):
     @once_differentiable
     def backward(ctx, d_loc, d_attn):
         attn, ref = ctx.saved_tensors
-        d_loc = torch.zeros_like(attn).unsqueeze(-1).expand(*attn.shape, 2).contiguous() \
-            if d_loc is None else d_loc.contiguous()
-        d_attn = torch.zeros_like(attn) if d_attn is None else d_attn.contiguous()
-        d_both = torch.empty(ctx.shape, device=attn.device, dtype=torch.float32)
-        with torch.cuda.device(attn.device):
-            rc = _native.lib.datr_msda_prologue_backward_f32(
-                d_loc.data_ptr(), d_attn.data_ptr(), attn.data_ptr(), ref.data_ptr(),
-                d_both.numel() // 384, ref.shape[-1], d_both.data_ptr(),
-                _native.current_stream_ptr(attn.device))
-        _native.check(rc, "msda_prologue_backward")
-        return d_both, None
+        return _prologue_backward(d_loc, d_attn, attn, ref, ctx.shape), None
 
 
+class _PrologueMSDA(Function):
+    """_Prologue and MSDeformAttnFunction of an encoder self-attention call (2-d reference points, the division by
+    (W_l, H_l) folded into the projection: locations = reference + offsets) as ONE node, for its backward: the
+    LDS-window kernel that computes grad_sampling_loc / grad_attn_weight writes the query projection's gradient rows
+    itself (softmax backward included), where the two nodes wrote 136 MB per call for a separate pass to re-arrange
+    (ms_deform_attn.py:94-113).  Returns (output, sampling locations); the locations carry no gradient (the offset
+    monitor reads them)."""
+
+    @staticmethod
+    def forward(ctx, both, ref, value, shapes, lsi, im2col_step, route, envelope):
+        both, ref = both.contiguous(), ref.contiguous()
+        loc, attn = _prologue_forward(both, ref)
+        ctx.im2col_step, ctx.route, ctx.shape = im2col_step, int(route), both.shape
+        kw = {"route": ctx.route} if ctx.route else {}
+        if envelope is not None:
+            import numpy as np
+            envelope = np.ascontiguousarray(envelope, dtype=np.float32)
+            if envelope.shape != (8, 4, 4):
+                raise ValueError(f"offset envelope must be [8, 4, 4], got {envelope.shape}")
+            kw["envelope"] = envelope
+        ctx.envelope = envelope
+        out = ms_deform_attn_forward(value, shapes, lsi, loc, attn, im2col_step, **kw)
+        ctx.save_for_backward(value, shapes, lsi, loc, attn, ref)
+        ctx.mark_non_differentiable(loc)
+        return out, loc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output, _unused):
+        value, shapes, lsi, loc, attn, ref = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        if ctx.route == 0 and QUERY_GRAD_BACKWARD:
+            kw = {} if ctx.envelope is None else {"envelope": ctx.envelope}
+            done = ms_deform_attn_backward_query_grad(value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step, **kw)
+            if done is not None:
+                return done[1].view(ctx.shape), None, done[0], None, None, None, None, None
+        kw = {"route": ctx.route} if ctx.route else {}
+        if ctx.envelope is not None:
+            kw["envelope"] = ctx.envelope
+        grad_value, grad_loc, grad_attn = ms_deform_attn_backward(value, shapes, lsi, loc, attn, grad_output,
+                                                                  ctx.im2col_step, **kw)
+        return _prologue_backward(grad_loc, grad_attn, attn, ref, ctx.shape), None, grad_value, None, None, None, None, None
+
+
+QUERY_GRAD_BACKWARD = __import__("os").environ.get("DATR_MSDA_QUERY_GRAD", "1") != "0"   # A/B switch
 FUSED_PROLOGUE = __import__("os").environ.get("DATR_FUSED_PROLOGUE", "1") != "0"      # A/B switch
 _INV_WH = {}
 
@@ -741,14 +830,23 @@ class MSDeformAttn(nn.Module):
                     and both.dtype == torch.float32 and not reference_points.requires_grad \
                     and reference_points.shape[-1] in (2, 4) \
                     and (fold_wh or reference_points.shape[-1] == 4) and value.dtype == torch.float32:
-                locations, weights = _Prologue.apply(both, reference_points.float())
-                route, envelope = 0, None
+                route, envelope, mon = 0, None, None
                 if fold_wh and ADAPTIVE_ROUTING and Len_q == Len_in:       # encoder self-attention
                     mon = _MONITORS.get(self)
                     if mon is None:
                         mon = _MONITORS[self] = OffsetMonitor()
                     route = mon.poll()
                     envelope = mon.envelope
+                if fold_wh and Len_q == Len_in and grad_slot is None and QUERY_GRAD_BACKWARD:
+                    # encoder self-attention: one node, whose backward leaves the projection's gradient rows
+                    out, locations = _PrologueMSDA.apply(both, reference_points.float(), value, input_spatial_shapes,
+                                                         input_level_start_index, self.im2col_step, route, envelope)
+                    if mon is not None:
+                        mon.observe(locations, _host_meta(_as_int64(input_spatial_shapes),
+                                                          _as_int64(input_level_start_index))[0])
+                    return self.output_proj(out)
+                locations, weights = _Prologue.apply(both, reference_points.float())
+                if mon is not None:
                     mon.observe(locations, _host_meta(_as_int64(input_spatial_shapes),
                                                       _as_int64(input_level_start_index))[0])
                 out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,

@@ -112,6 +112,20 @@ int datr_msda_backward_pyramid_f32(const float *grad_out, const float *value, co
                                    const float *loc, const float *attn, int64_t N, int64_t S, int64_t M,
                                    int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value,
                                    float *grad_loc, float *grad_attn, void *stream);
+/* The encoder calls' backward for the MSDeformAttn MODULE (ms_deform_attn.py:94-113): sampling locations and
+ * attention weights come from ONE projection of the query (offsets | logits, M * 48 = 384 columns for M = 8 heads,
+ * the division by (W_l, H_l) folded into its weights), so what the module's backward needs is the gradient of that
+ * projection's output, grad_query [N * Lq, M * 48]: columns [m][l][p][2] = grad_sampling_loc, then [m][l * 4 + p] =
+ * the softmax backward a (g - sum a g) of grad_attn_weight.  The LDS-window kernel writes those rows directly
+ * instead of grad_loc / grad_attn followed by a pass that re-arranges them (msda_prologue.hip); grad_value as in
+ * datr_msda_backward_pyramid_f32.  `attn` = the softmax OUTPUT, as everywhere.  DATR_EUNSUPPORTED (grad_query
+ * untouched; the caller takes datr_msda_backward_pyramid_f32 + datr_msda_prologue_backward_f32) unless Lq == S,
+ * M == 8, D == 32, L == P == 4 and the LDS-window plan covers the shape. */
+int datr_msda_backward_pyramid_query_f32(const float *grad_out, const float *value, const int64_t *shapes_host,
+                                         const int64_t *level_start_host, const float *envelope_host,
+                                         const float *loc, const float *attn, int64_t N, int64_t S, int64_t M,
+                                         int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value,
+                                         float *grad_query, void *stream);
 /* The decoder calls' backward (few, spatially unordered queries: Lq != S, Lq <= 4096, D == 32) with
  * grad_value rows `grad_value_row_stride` floats apart (>= M * D): the six decoder layers of
  * /root/reference/models/dino/deformable_transformer.py:880-900 write their value gradients as column

@@ -739,3 +739,94 @@ def test_batched_value_projections_match_separate_modules(M, dev):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     for a, b in zip(g1, g2):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(a.abs().max()))
+
+
+@pytest.mark.parametrize("kind,N", [("ring", 4), ("gauss", 2)])
+def test_encoder_backward_query_gradient_rows_against_oracle(M, O, dev, kind, N):
+    """datr_msda_backward_pyramid_query_f32 (ms_deform_attn_backward_query_grad): the encoder call's backward
+    leaving the gradient of the module's merged query projection -- [grad_sampling_loc | softmax backward of
+    grad_attn_weight] in rows of 384 -- at the training step's size against the C oracle's grad_loc / grad_attn
+    pushed through the softmax backward in float64 (ms_deform_attn.py:106), and against the two-pass route
+    (ms_deform_attn_backward + the prologue's backward kernel) it replaces."""
+    Mh, D, P = 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, FULL_SHAPES, P, seed=51)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(52)
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    if kind == "ring":
+        ring = M.MSDeformAttn(256, 4, Mh, P).sampling_offsets.bias.detach().view(1, 1, Mh, 4, P, 2)
+        wh = torch.tensor([[w, h] for h, w in FULL_SHAPES], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+        loc = (pyramid_locs(FULL_SHAPES, N, Mh, P, 0.05, seed=53) + ring / wh).contiguous()
+    else:
+        loc = pyramid_locs(FULL_SHAPES, N, Mh, P, 3.0, seed=53)
+    go = torch.randn(N, S, Mh * D, generator=g)
+    d = [t.to(dev) for t in (value, sh, lsi, loc, attn, go)]
+    import numpy as np
+    # ring: the measured envelope, every sample inside its window; gauss (sigma 3 px): windows of +-2.5 px, so that
+    # a good part of the samples goes through the kernel's global-memory path (results never depend on the envelope)
+    env = M.measure_envelope(d[3], d[1]) if kind == "ring" else np.tile(np.array([-2.5, 2.5, -2.5, 2.5], np.float32), (8, 4, 1))
+    plan = M.pyramid_plan(d[1], d[2], N, Mh, D, P, env)
+    done = M.ms_deform_attn_backward_query_grad(d[0], d[1], d[2], d[3], d[4], d[5], 64, envelope=env)
+    assert plan["phased"] and plan["tasks_per_wave"] == (2 if kind == "ring" else 3), plan     # both kernel variants
+    assert done is not None
+    gv, gq = done
+    assert gq.shape == (N, S, 384)
+    rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
+    scale = float(rv.abs().max())
+    torch.testing.assert_close(gv.cpu(), rv, rtol=1e-3, atol=1e-5 * scale)
+    a64, g64 = attn.double().view(N, S, Mh, 16), ra.double().view(N, S, Mh, 16)
+    dlogit = (a64 * (g64 - (a64 * g64).sum(-1, keepdim=True))).float().view(N, S, 128)
+    torch.testing.assert_close(gq[..., 256:].cpu(), dlogit, rtol=1e-4, atol=1e-5 * float(dlogit.abs().max()))
+    keep = off_grid(loc, sh)
+    torch.testing.assert_close(gq[..., :256].cpu().view(N, S, Mh, 4, P, 2)[keep], rl[keep], **tol(torch.float32, 100))
+    # the two-pass route: the same kernels followed by csrc/msda_prologue.hip's backward
+    gv2, gl2, ga2 = M.ms_deform_attn_backward(d[0], d[1], d[2], d[3], d[4], d[5], 64, envelope=env)
+    ref2 = torch.zeros(N, S, 4, 2, device=dev)
+    both2 = M._prologue_backward(gl2, ga2, d[4].view(N, S, Mh, 4, P), ref2, (N, S, 384))
+    assert torch.equal(gq[..., :256], both2[..., :256])                  # grad_loc: the same values, another place
+    torch.testing.assert_close(gq[..., 256:], both2[..., 256:], rtol=1e-5, atol=1e-6 * float(dlogit.abs().max()))
+
+
+def test_query_gradient_backward_declines_what_it_does_not_cover(M, O, dev):
+    """Decoder-like calls (Lq != S) return None: the module then takes the two-pass route."""
+    value, sh, lsi, loc, attn = O.random_inputs(2, 300, 8, 32, [(25, 34), (13, 17), (7, 9), (4, 5)], 4, seed=5)
+    d = [t.to(dev) for t in (value, sh, lsi, loc, attn)]
+    go = torch.randn(2, 300, 256, device=dev)
+    assert M.ms_deform_attn_backward_query_grad(d[0], d[1], d[2], d[3], d[4], go, 64) is None
+
+
+def test_module_with_query_gradient_node_equals_the_two_node_module(M, dev, monkeypatch):
+    """MSDeformAttn.forward on an encoder self-attention call: the one-node form (_PrologueMSDA, backward through
+    datr_msda_backward_pyramid_query_f32) against the two nodes (DATR_MSDA_QUERY_GRAD=0): output bitwise equal,
+    gradients of query / input / parameters equal to fp32 rounding (float atomics in grad_value)."""
+    torch.manual_seed(11)
+    shapes = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes)
+    attn_mod = M.MSDeformAttn(256, 4, 8, 4).to(dev)
+    sh = torch.tensor(shapes, device=dev)
+    lsi = torch.cat([sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]])
+    ref = torch.cat([torch.stack(torch.meshgrid(
+        (torch.arange(h, device=dev) + 0.5) / h, (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"), -1)
+        .flip(-1).reshape(-1, 2) for h, w in shapes], 0)[None, :, None, :].expand(2, S, 4, 2).contiguous()
+    q = torch.randn(2, S, 256, device=dev, requires_grad=True)
+    x = torch.randn(2, S, 256, device=dev, requires_grad=True)
+    go = torch.randn(2, S, 256, device=dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(M, "QUERY_GRAD_BACKWARD", on)
+        y = attn_mod(q, ref, x, sh, lsi, None)
+        names = []
+        fn = y.grad_fn
+        seen, todo = set(), [fn]
+        while todo:
+            f = todo.pop()
+            if f is None or f in seen:
+                continue
+            seen.add(f)
+            names.append(type(f).__name__)
+            todo.extend(n for n, _ in f.next_functions)
+        assert any("PrologueMSDA" in n for n in names) == on
+        res[on] = (y, torch.autograd.grad(y, [q, x] + list(attn_mod.parameters()), go))
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7

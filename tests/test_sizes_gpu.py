@@ -60,7 +60,14 @@ def test_training_step_at_the_real_c2f_size():
     def bwd(value, *a, **kw):
         calls["bwd"] += value.shape[1] == S and a[2].shape[1] == S
         return orig_b(value, *a, **kw)
+    orig_q = msda.ms_deform_attn_backward_query_grad
+
+    def bwd_q(value, *a, **kw):                     # the module's entry to the same two kernels
+        done = orig_q(value, *a, **kw)
+        calls["bwd"] += done is not None and value.shape[1] == S
+        return done
     msda.ms_deform_attn_forward, msda.ms_deform_attn_backward = fwd, bwd
+    msda.ms_deform_attn_backward_query_grad = bwd_q
     try:
         stats = run_steps(state, [pool[i % 2] for i in range(3)])       # warm-up; raises on any native error code
         torch.cuda.synchronize()
@@ -71,6 +78,7 @@ def test_training_step_at_the_real_c2f_size():
         ms = (time.perf_counter() - t0) / n * 1e3
     finally:
         msda.ms_deform_attn_forward, msda.ms_deform_attn_backward = orig_f, orig_b
+        msda.ms_deform_attn_backward_query_grad = orig_q
     assert calls["fwd"] == 6 * 7 and calls["bwd"] == 6 * 7, calls    # six encoder layers, merged N = 2 pass
     assert np.isfinite(stats["loss"]) and stats["loss"] > 0
     for k, v in stats.items():

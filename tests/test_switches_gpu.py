@@ -40,6 +40,7 @@ GROUPS = {
                                        "DATR_OWN_ATTENTION": "0"},
     "msda-routes": {"DATR_MSDA_PYR_FWD": "0", "DATR_MSDA_PYR_BWD": "0", "DATR_MSDA_ADAPTIVE": "0"},
     "msda-one-kernel-backward": {"DATR_MSDA_BWD_SPLIT": "0", "DATR_MSDA_PYR2": "0", "DATR_MSDA_PYRB_WIDEN": "0"},
+    "msda-two-node-module": {"DATR_MSDA_QUERY_GRAD": "0"},
     "library-convolutions": {"DATR_OWN_BOTTLENECK": "0", "DATR_OWN_CONV3X3": "0", "DATR_OWN_CONV_S2": "0",
                              "DATR_OWN_D_IMG": "0", "DATR_OWN_CLASSIFIER": "0", "DATR_CONV1X1_GEMM": "0", "DATR_MIOPEN_DB": "1"},
     "per-op-backbone": {"DATR_OWN_BOTTLENECK": "0", "DATR_OWN_D_IMG_WGRAD": "0", "DATR_OVERLAP_D_IMG": "0",
