@@ -205,12 +205,22 @@ def _linear_fwd(x2: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.T
     return torch.addmm(b, x2, w.t()) if out is None else torch.addmm(b, x2, w.t(), out=out)
 
 
-def _dgrad(dy2: torch.Tensor, w: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
-    """dy2 W (+ residual): the data gradient of a linear layer, library GEMM or the own NN form."""
+def _dgrad(dy2: torch.Tensor, w: torch.Tensor, residual: torch.Tensor = None, consume: bool = False) -> torch.Tensor:
+    """dy2 W (+ residual): the data gradient of a linear layer, library GEMM or the own NN form.
+    consume: `residual` is the caller's own scratch and may hold the result -- the library GEMM then accumulates
+    into it (beta = 1, C = D) where `torch.addmm` first copies the residual into a new result (33 us per encoder
+    layer for the 91-MB token tensor)."""
     from . import gemm
     if gemm.own_big(dy2, w) and (residual is None or gemm.own_big(residual)):
         return gemm.gemm_nn(dy2, w, residual=residual)
-    return dy2.mm(w) if residual is None else torch.addmm(residual, dy2, w)
+    if residual is None:
+        return dy2.mm(w)
+    if consume and residual.is_contiguous() and ADDMM_IN_PLACE:
+        return residual.addmm_(dy2, w)
+    return torch.addmm(residual, dy2, w)
+
+
+ADDMM_IN_PLACE = os.environ.get("DATR_ADDMM_IN_PLACE", "1") != "0"       # A/B switch
 
 
 def _wgrad_mm(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
@@ -432,7 +442,7 @@ class _FFNAddNorm(Function):
             db2 = None
         dh, db1 = _ffn_hidden_gradient(dsum, w2, h)
         dw1 = _ffn_wgrad(dh, x2, need[1], False)[0]
-        dx = _dgrad(dh, w1, residual=dsum).view(ctx.shape) if need[0] else None
+        dx = _dgrad(dh, w1, residual=dsum, consume=True).view(ctx.shape) if need[0] else None     # dsum's last use
         return (dx, dw1, db1 if need[2] else None, dw2, db2, dgamma if need[5] else None,
                 dbeta if need[6] else None, None, dpos)
 

@@ -485,12 +485,15 @@ class _PrologueMSDA(Function):
         out = ms_deform_attn_forward(value, shapes, lsi, loc, attn, im2col_step, **kw)
         ctx.save_for_backward(value, shapes, lsi, loc, attn, ref)
         ctx.mark_non_differentiable(loc)
+        ctx.set_materialize_grads(False)        # no 91-MB zero gradient for the locations
         return out, loc
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output, _unused):
         value, shapes, lsi, loc, attn, ref = ctx.saved_tensors
+        if grad_output is None:
+            return (None,) * 8
         grad_output = grad_output.contiguous()
         if ctx.route == 0 and QUERY_GRAD_BACKWARD:
             kw = {} if ctx.envelope is None else {"envelope": ctx.envelope}
