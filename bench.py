@@ -158,7 +158,24 @@ class MsdaTimer:
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "kernel": kernel, "launches": len(us),
-                "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes}
+                "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes,
+                "empty_event_pair_us": empty_event_pair_us()}
+
+
+def empty_event_pair_us(n: int = 64):
+    """What a HIP event pair reads with NOTHING between the two records, on the stream the kernels run on: the part
+    of `mean_us` above that is bracketing, not kernel (reported beside it, never subtracted; the rocprofv3 tables
+    under profiles/ hold the kernel's own duration)."""
+    torch.cuda.synchronize()
+    pairs = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+    return round(us[len(us) // 2], 2)
 
 
 def msda_rand_roofline(device, shape):
