@@ -50,15 +50,27 @@ __global__ __launch_bounds__(kThreads) void c1_fwd(const float *__restrict__ x, 
     for (long p = (long)blockIdx.x * kPixPerBlock + sub; p < npix; p += (long)gridDim.x * kPixPerBlock) {
         const int xw = (int)(p % W), yh = (int)((p / W) % H);
         const float *px = x + p * kC + lane32 * 4;
-        float acc = 0.f;
+        // Branch-free taps: a neighbour outside the image is read at its clamped position and dropped by a select, so
+        // the nine 16-byte loads of a pixel leave together (with a bounds branch per tap each load waited for the one
+        // before it: load, s_waitcnt vmcnt(0), nine times).  Same sums in the same order.
+        f4 v[9];
+        bool in[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int yy = yh + ky - 1, xx = xw + kx - 1;
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    acc += dot4(*reinterpret_cast<const f4 *>(px + ((ky - 1) * W + (kx - 1)) * kC), wt[ky * 3 + kx]);
+                in[ky * 3 + kx] = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+                const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+                v[ky * 3 + kx] = *reinterpret_cast<const f4 *>(px + ((yc - yh) * W + (xc - xw)) * kC);
             }
+        __builtin_amdgcn_sched_barrier(0);           // all nine requests first (the scheduler otherwise re-uses one register set)
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float d = dot4(v[t], wt[t]);
+            acc += in[t] ? d : 0.f;
+        }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 32);
         if (lane32 == 0) y[p] = acc + b;
@@ -75,17 +87,22 @@ __global__ __launch_bounds__(kThreads) void c1_dgrad(const float *__restrict__ d
     const long npix = (long)N * H * W;
     for (long p = (long)blockIdx.x * kPixPerBlock + sub; p < npix; p += (long)gridDim.x * kPixPerBlock) {
         const int xw = (int)(p % W), yh = (int)((p / W) % H);
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const f4 av = *reinterpret_cast<const f4 *>(a + p * kC + lane32 * 4);
+        float g[9];                                  // branch-free as in c1_fwd: clamped reads, selects
+        bool in[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 // output pixel q = p - (k - 1) saw input pixel p through tap k
                 const int yy = yh - (ky - 1), xx = xw - (kx - 1);
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    acc += dy[p - ((ky - 1) * W + (kx - 1))] * wt[ky * 3 + kx];
+                in[ky * 3 + kx] = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+                const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+                g[ky * 3 + kx] = dy[p + ((yc - yh) * W + (xc - xw))];
             }
-        const f4 av = *reinterpret_cast<const f4 *>(a + p * kC + lane32 * 4);
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += (in[t] ? g[t] : 0.f) * wt[t];
         f4 out;
         out.x = av.x > 0.f ? acc.x : acc.x * slope;
         out.y = av.y > 0.f ? acc.y : acc.y * slope;
@@ -109,14 +126,19 @@ __global__ __launch_bounds__(kThreads) void c1_wgrad(const float *__restrict__ a
         const int xw = (int)(p % W), yh = (int)((p / W) % H);
         const f4 av = *reinterpret_cast<const f4 *>(a + p * kC + lane32 * 4);
         db += dy[p];
+        float g[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int yy = yh - (ky - 1), xx = xw - (kx - 1);
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    acc[ky * 3 + kx] += dy[p - ((ky - 1) * W + (kx - 1))] * av;
+                const bool in = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+                const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+                const float d = dy[p + ((yc - yh) * W + (xc - xw))];
+                g[ky * 3 + kx] = in ? d : 0.f;
             }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += g[t] * av;
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) red[sub][t][lane32] = acc[t];

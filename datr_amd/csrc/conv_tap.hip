@@ -219,6 +219,20 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
         }
     }
     const float slope = raw ? 1.f : a.slope;
+    // Stores through a buffer descriptor with 32-bit offsets (the host checks that the output and the partial buffer
+    // stay below 2 GiB): a position outside the map gets an out-of-range offset and its store is dropped -- no branch
+    // per position -- and scale / shift are settled before the first store.  With bounds branches around the stores the
+    // compiler waited for everything in flight, the previous store included, ahead of every position (s_waitcnt vmcnt(0)
+    // 23 times per lane).
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0x7ffffffc, 0x00020000);
+    const unsigned ch_off = (unsigned)(co0 + wn * (BNT / 2) + l31) * 4u;
+    // output pixel of position (oy, ox) = pix0 + oy pix_sy + ox pix_sx: the partial buffer [z][n][Hidx][Widx] of a split
+    // launch (single-class launches only) or the strided place in the output tensor
+    const int nimg = (int)gridDim.x / (c.tiles_x * c.tiles_y);
+    const int pix0 = raw ? ((int)blockIdx.z * nimg + n) * c.Hidx * c.Widx : (n * a.Hout + c.OOy) * a.Wout + c.OOx;
+    const int pix_sy = raw ? c.Widx : a.OS * a.Wout, pix_sx = raw ? 1 : a.OS;
+    const int Hi = c.Hidx, Wi = c.Widx;
+    asm volatile("" : : "v"(sc[0]), "v"(sc[1]), "v"(sh[0]), "v"(sh[1]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -226,19 +240,13 @@ __global__ __launch_bounds__(kThreads) void tap_conv(const TapArgs a)
             const int prow = (e & 3) + 8 * (e >> 2) + 4 * lhi;          // position within the 32-block
             const int py = wm * 4 + i * 2 + (prow >> 4), px = prow & 15;
             const int oy = oy0 + py, ox = ox0 + px;
-            if (oy < c.Hidx && ox < c.Widx) {
-                float *yb;
-                if (raw)         // (single-class launches only)
-                    yb = a.y + ((((size_t)blockIdx.z * gridDim.x / (c.tiles_x * c.tiles_y) + n) * c.Hidx + oy) * c.Widx + ox) * Cout;
-                else
-                    yb = a.y + (((size_t)n * a.Hout + oy * a.OS + c.OOy) * a.Wout + ox * a.OS + c.OOx) * Cout;
-                yb += co0 + wn * (BNT / 2) + l31;
+            const unsigned pix = (unsigned)(pix0 + oy * pix_sy + ox * pix_sx);
+            const unsigned off = ((oy < Hi) & (ox < Wi)) ? pix * (unsigned)Cout * 4u + ch_off : 0x80000000u;
 #pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    float v = acc[i][jn][e] * sc[jn] + sh[jn];
-                    v = v > 0.f ? v : v * slope;
-                    yb[jn * 32] = v;
-                }
+            for (int jn = 0; jn < NJ; ++jn) {
+                float v = acc[i][jn][e] * sc[jn] + sh[jn];
+                v = v > 0.f ? v : v * slope;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ysrc, off, jn * 128, 0);
             }
         }
     }
@@ -335,6 +343,8 @@ int launch_taps(int IS, const float *x, const float *wt, const float *scale, con
     if (ksplit > 1 && (!partial || partial_floats < per_split * ksplit)) ksplit = 1;
     a.ksplit = ksplit;
     a.y = ksplit > 1 ? partial : y;
+    // the kernel's stores use 32-bit byte offsets
+    if ((ksplit > 1 ? per_split * ksplit : (long)N * Hout * Wout * Cout) * 4 >= (1L << 31)) return DATR_EUNSUPPORTED;
     const size_t lds = (size_t)patch_floats * sizeof(float);
     dim3 grid((unsigned)tiles, (unsigned)(Cout / 128), (unsigned)ksplit);
     auto go = [&](auto kernel) {

@@ -98,17 +98,22 @@ __global__ __launch_bounds__(kThreads, 2) void stem_conv(const float *__restrict
         int b = tile;
         const int tx = b % tiles_x; b /= tiles_x;
         const int ty = b % tiles_y; b /= tiles_y;
+        // Stores through a per-image buffer descriptor: a position outside the map gets an out-of-range offset and is
+        // dropped, so there is no branch around the stores and the compiler knows how many are in flight -- the wait
+        // for the next tile's prefetched patch at the top of the loop then lets these 32 stores drain behind it
+        // (with bounds branches it waited for everything, s_waitcnt vmcnt(0), once per tile).
+        const int bu = __builtin_amdgcn_readfirstlane(b);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            y + (size_t)bu * Ho * Wo * 64, 0, Ho * Wo * 64 * 4, 0x00020000);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int prow = (e & 3) + 8 * (e >> 2) + 4 * lhi;          // position within the wave's 32
             const int oy = ty * TH + wave * 2 + (prow >> 4), ox = tx * TW + (prow & 15);
-            if (oy < Ho && ox < Wo) {
-                float *yb = y + (((size_t)b * Ho + oy) * Wo + ox) * 64 + l31;
+            const unsigned off = ((oy < Ho) & (ox < Wo)) ? (unsigned)(((oy * Wo + ox) * 64 + l31) * 4) : 0x80000000u;
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
-                    const float v = acc[jn][e] * sc[jn] + sh[jn];
-                    __builtin_nontemporal_store(v > 0.f ? v : 0.f, yb + jn * 32);
-                }
+            for (int jn = 0; jn < 2; ++jn) {
+                const float v = acc[jn][e] * sc[jn] + sh[jn];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v > 0.f ? v : 0.f), yr, off, jn * 128, 2);
             }
         }
     }
@@ -121,7 +126,7 @@ extern "C" int datr_stem_conv7x7_bn_relu_nhwc_f32(const float *x, const float *w
                                                   void *stream)
 {
     if (!x || !wk || !scale || !shift || !y || N < 0 || H < 1 || W < 1) return DATR_EINVAL;
-    if (H * W * 3 * 4 >= (1LL << 31)) return DATR_EUNSUPPORTED;
+    if (H * W * 3 * 4 >= (1LL << 31) || ((H + 1) / 2) * ((W + 1) / 2) * 64 * 4 >= (1LL << 31)) return DATR_EUNSUPPORTED;
     if (N == 0) return DATR_OK;
     const int Ho = (int)((H + 1) / 2), Wo = (int)((W + 1) / 2);
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;

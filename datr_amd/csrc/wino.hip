@@ -308,8 +308,26 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
     const float sc = scale ? scale[co] : 1.f;
     const float sh = shift ? shift[co] : 0.f;
     const float slope = args.slope, gslope = args.gate_slope, oscale = args.out_scale;
-    float *Yn = L.y + (size_t)n * H * W * Cout;
-    const float *Gn = L.gate ? L.gate + (size_t)n * H * W * Cout : nullptr;
+    // Output rows and gate values go through buffer descriptors with 32-bit offsets: a pixel outside the image gets
+    // an out-of-range offset (its store is dropped, its gate reads zero) -- no branch per element, no 64-bit address
+    // arithmetic.  All 32 gate values of the lane are requested TOGETHER and before the first store, and scale / shift
+    // are settled before the loop: written as one loop over (load gate, blend, store) with bounds branches, the compiler
+    // waited for EVERYTHING in flight -- the previous store included -- ahead of every element (vmcnt(0) 32 times:
+    // 163-178 us for the data-gradient launches of layer2 / layer3 against 112-125 us forward).
+    auto uniform_ptr = [](const float *p) {         // wave-uniform by construction (blockIdx only): say so, or the
+        const unsigned long long v = (unsigned long long)p;        // descriptor lands in VGPRs and every access in a waterfall loop
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (float *)(((unsigned long long)hi << 32) | lo);
+    };
+    const bool gated = __builtin_amdgcn_readfirstlane(L.gate != nullptr ? 1 : 0) != 0;
+    const int img_bytes = __builtin_amdgcn_readfirstlane(H * W * Cout * 4);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(L.y + (size_t)n * H * W * Cout), 0, img_bytes, 0x00020000);
+    // ungated: a descriptor of zero bytes -- every load is out of range and returns 0 without touching memory
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(gated ? L.gate + (size_t)n * H * W * Cout : L.y), 0, gated ? img_bytes : 0, 0x00020000);
+    unsigned ooff[2][16];
+    float gv[2][16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int tile = (e & 3) + 8 * (e >> 2) + 4 * lhi;
@@ -317,15 +335,20 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int xx = ox + j;
-            if (yy < H && xx < W) {
-                const size_t o = ((size_t)yy * W + xx) * Cout + co;
-                float v = (mine[j][e] + got[(j * 16 + e) * 64]) * sc + sh;
-                v = v > 0.f ? v : v * slope;
-                if (Gn) v = __builtin_nontemporal_load(&Gn[o]) > 0.f ? v : v * gslope;
-                __builtin_nontemporal_store(v * oscale, &Yn[o]);
-            }
+            ooff[j][e] = (yy < H && xx < W) ? (unsigned)(((yy * W + xx) * Cout + co) * 4) : 0x80000000u;
+            gv[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gsrc, ooff[j][e], 0, 2));
         }
     }
+    asm volatile("" : : "v"(sc), "v"(sh));        // scale / shift have landed before the first store is issued
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v = (mine[j][e] + got[(j * 16 + e) * 64]) * sc + sh;
+            v = v > 0.f ? v : v * slope;
+            v = (!gated || gv[j][e] > 0.f) ? v : v * gslope;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v * oscale), ysrc, ooff[j][e], 0, 2);
+        }
 }
 
 // U[pos][Cin/8][Cout][8] = G g G^T of every (ci, co) filter, the 8 channels of a block in the order the MFMA
@@ -414,6 +437,7 @@ extern "C" int datr_conv3x3_wino_nhwc_f32(const datr_wino_level *levels, int64_t
         if (i < nlevels) {
             if (!s.x || !s.y || s.H <= 0 || s.W <= 0) return DATR_EINVAL;
             if (N * s.H * s.W * (Cin > Cout ? Cin : Cout) > 0x7fffffffLL) return DATR_EUNSUPPORTED;
+            if (s.H * s.W * (Cin > Cout ? Cin : Cout) * 4 > 0x7fffffffLL) return DATR_EUNSUPPORTED;   // per-image buffer descriptors
         }
         WinoLevel &d = a.lv[i];
         d.x = s.x; d.y = s.y; d.gate = s.gate; d.H = (int)s.H; d.W = (int)s.W;
