@@ -29,10 +29,30 @@ __global__ __launch_bounds__(64 * kSlices) void prototypes_fwd(
     __shared__ float cnt[kSlices];
     const int k = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     float acc = 0.f, n = 0.f;
-    for (int r = sl; r < R; r += kSlices) {
-        const bool mine = labels[r] == k;                 // uniform over the wave
-        if (mine) { acc += feats[(size_t)r * C + c]; n += 1.f; }
-        if (blockIdx.y == 0 && (threadIdx.x & 63) == 0) onehot[(size_t)r * K + k] = mine ? 1.f : 0.f;
+    // Eight rows of the slice at a time: their labels, then their feature values, are requested together (row by row,
+    // each label decided whether the feature was read at all: two dependent memory latencies per row: 82 -> 57 us for
+    // 4 400 rows).  Rows that are not the class's are read at row 0 and dropped by a select; the sums run in the same
+    // order as before.  (Measured and not kept: reading every row's value without waiting for its label, 68 us;
+    // thirty-two rows at a time spills at 1 024 threads per workgroup, 4 x slower.)
+    constexpr int kUnroll = 8;
+    for (int r0 = sl; r0 < R; r0 += kSlices * kUnroll) {
+        bool mine[kUnroll];
+        float v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int r = r0 + u * kSlices;
+            const int64_t lab = labels[min(r, R - 1)];        // no branch around the load: eight requests in flight
+            mine[u] = (r < R) & (lab == k);                   // uniform over the wave
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = feats[(size_t)(mine[u] ? r0 + u * kSlices : 0) * C + c];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int r = r0 + u * kSlices;
+            acc += mine[u] ? v[u] : 0.f;
+            n += mine[u] ? 1.f : 0.f;
+            if (r < R && blockIdx.y == 0 && (threadIdx.x & 63) == 0) onehot[(size_t)r * K + k] = mine[u] ? 1.f : 0.f;
+        }
     }
     red[sl][threadIdx.x & 63] = acc;
     if ((threadIdx.x & 63) == 0) cnt[sl] = n;
