@@ -77,7 +77,14 @@ constexpr int TBY = 4, TBX = 8;                // tiles per workgroup
 constexpr int PH = 2 * TBY + 2, PW = 2 * TBX + 2;   // 10 x 18 patch
 constexpr int PPIX = PH * PW;                  // 180
 constexpr int CK = 4;
-constexpr int kPatchF = PPIX * 4;              // floats: [pixel][4]
+// raw patch in LDS: [row][column parity][10 pixel slots][4 channels] -- a row is 320 B.  A transform thread reads
+// pixels 2 t_tx + {0..3} of rows 2 t_ty + {0..3}: with even and odd columns in separate planes the eight tiles of a
+// tile row read 128 contiguous bytes, and two patch rows down (the next tile row, the other half of a 16-lane LDS
+// phase) is 640 B = 128 B further in the bank map: conflict free.  ([pixel][4] with 18 pixels per row put every second
+// tile of the two tile rows of a phase on the same banks: 57 % of the kernel's LDS cycles were bank conflicts.)
+constexpr int kPatchRowF = 80;
+constexpr int kPatchF = PH * kPatchRowF;       // floats
+__device__ __forceinline__ int patch_off(int py, int px) { return py * kPatchRowF + (px & 1) * 40 + (px >> 1) * 4; }
 constexpr int kVPos = 32 * 4;                  // floats between positions of V: [pos][tile][4]
 constexpr int kVF = 16 * kVPos;
 constexpr int kXchF = 4 * 32 * 64;             // the inverse transform's exchange buffer (re-uses everything)
@@ -150,8 +157,9 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
         const auto r_ = __builtin_amdgcn_raw_buffer_load_b128(xsrc, poff, c * CK * 4, 0);
         pf = __builtin_bit_cast(float4, r_);
     };
+    const int pdst = patch_off(tid / PW, tid % PW);        // this thread's pixel of the raw patch
     auto store_patch = [&](float *dst) {
-        if (tid < PPIX) *reinterpret_cast<float4 *>(&dst[tid * 4]) = pf;
+        if (tid < PPIX) *reinterpret_cast<float4 *>(&dst[pdst]) = pf;
     };
 
     // transform unit of this thread: (tile, ONE transform row xi = 2 rp + q, the column pair 2 cp, 2 cp + 1);
@@ -162,10 +170,12 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
     const int t_tile = lane & 31, t_q = lane >> 5;
     const int t_rp = wave & 1, t_cp = wave >> 1;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    const int p_base = (2 * t_ty * PW + 2 * t_tx) * 4;
+    const int p_base = 2 * t_ty * kPatchRowF + t_tx * 4;
     const int rowA = t_rp ? 2 : 0, rowB = t_rp ? 1 : 2, rowC = t_rp ? 3 : 1;
-    const int r_off[2] = {rowB * PW * 4, (t_q ? rowC : rowA) * PW * 4};
-    const int c_off[3] = {(t_cp ? 2 : 0) * 4, (t_cp ? 1 : 2) * 4, (t_cp ? 3 : 1) * 4};
+    const int r_off[2] = {rowB * kPatchRowF, (t_q ? rowC : rowA) * kPatchRowF};
+    // patch column 2 t_tx + cx sits in plane cx & 1 at slot t_tx + (cx >> 1)
+    auto col = [](int cx) { return (cx & 1) * 40 + (cx >> 1) * 4; };
+    const int c_off[3] = {col(t_cp ? 2 : 0), col(t_cp ? 1 : 2), col(t_cp ? 3 : 1)};
     const float alpha = t_q ? (t_rp ? -1.f : 1.f) : -1.f, s_c = t_cp ? -1.f : 1.f;
     const int v_off = (((2 * t_rp + t_q) * 4 + 2 * t_cp) * 32 + t_tile) * 4;
 
@@ -198,8 +208,8 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
 #pragma unroll
         for (int p = 0; p < 8; ++p) bq[p] = load_b(0, p);
         if (tid < PPIX) {
-            *reinterpret_cast<float4 *>(&patch[tid * 4]) = __builtin_bit_cast(float4, r0);
-            *reinterpret_cast<float4 *>(&patch[kPatchF + tid * 4]) = __builtin_bit_cast(float4, r1);
+            *reinterpret_cast<float4 *>(&patch[pdst]) = __builtin_bit_cast(float4, r0);
+            *reinterpret_cast<float4 *>(&patch[kPatchF + pdst]) = __builtin_bit_cast(float4, r1);
         }
     }
     __syncthreads();
