@@ -29,8 +29,9 @@
 // multiplies in TWO consecutive chunks in one 16-byte load (U[pos][Cin/8][Cout][8], wino_weights);
 // there is one register set, refilled position by position as the odd chunk of a pair finishes with
 // them.  A k-step multiplies channels (m, 2 + m) of the
-// chunk: lane half `lhi` reads channels 2 lhi, 2 lhi + 1 of its tile with one ds_read_b64 (64 lanes x
-// 8 B = 512 dense bytes: conflict free).  The inverse transform A^T M A is lane-local up to one
+// chunk: lane half `lhi` reads channels 2 lhi, 2 lhi + 1 of its tile with one ds_read_b64; V is laid out
+// [pos][channel half][tile][2], so each 32-lane pass of the read covers 256 contiguous bytes (round 5; with
+// [pos][tile][4] the lanes of a pass sat 16 B apart: two-way bank conflicts, measured).  The inverse transform A^T M A is lane-local up to one
 // exchange of 32 floats per lane between the two position halves (through LDS, once per workgroup),
 // and a lane's 32-lane row stores 128 contiguous bytes of NHWC output (non-temporal: -3 %).  All
 // levels of the pyramid share the filter, so they are ONE launch (level table in the arguments).
@@ -85,7 +86,8 @@ constexpr int CK = 4;
 constexpr int kPatchRowF = 80;
 constexpr int kPatchF = PH * kPatchRowF;       // floats
 __device__ __forceinline__ int patch_off(int py, int px) { return py * kPatchRowF + (px & 1) * 40 + (px >> 1) * 4; }
-constexpr int kVPos = 32 * 4;                  // floats between positions of V: [pos][tile][4]
+constexpr int kVPos = 32 * 4;                  // floats between positions of V: [pos][channel half][tile][2] -- the 32 lanes of a
+                                               // ds_read_b64 pass read 256 contiguous bytes ([pos][tile][4] put them 16 B apart: two-way conflicts)
 constexpr int kVF = 16 * kVPos;
 constexpr int kXchF = 4 * 32 * 64;             // the inverse transform's exchange buffer (re-uses everything)
 constexpr int kLdsBytes = (2 * kPatchF + 3 * kVF > kXchF ? 2 * kPatchF + 3 * kVF : kXchF) * 4;   // 32 KB
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
     auto col = [](int cx) { return (cx & 1) * 40 + (cx >> 1) * 4; };
     const int c_off[3] = {col(t_cp ? 2 : 0), col(t_cp ? 1 : 2), col(t_cp ? 3 : 1)};
     const float alpha = t_q ? (t_rp ? -1.f : 1.f) : -1.f, s_c = t_cp ? -1.f : 1.f;
-    const int v_off = (((2 * t_rp + t_q) * 4 + 2 * t_cp) * 32 + t_tile) * 4;
+    const int v_off = ((2 * t_rp + t_q) * 4 + 2 * t_cp) * kVPos + t_tile * 2;
 
     float4 d[2][3];
     auto f4fma = [](float s_, float4 b, float4 c) {
@@ -195,8 +197,11 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) tq[cc] = f4fma(alpha, d[0][cc], d[1][cc]);
         float *vb = vbuf + v_off;
-        *reinterpret_cast<float4 *>(vb) = f4sub(tq[0], tq[1]);
-        *reinterpret_cast<float4 *>(vb + kVPos) = f4fma(s_c, tq[1], tq[2]);
+        const float4 v0 = f4sub(tq[0], tq[1]), v1 = f4fma(s_c, tq[1], tq[2]);
+        *reinterpret_cast<float2 *>(vb) = make_float2(v0.x, v0.y);                  // channels 0, 1: lane half 0's k-steps
+        *reinterpret_cast<float2 *>(vb + 64) = make_float2(v0.z, v0.w);             // channels 2, 3: lane half 1's
+        *reinterpret_cast<float2 *>(vb + kVPos) = make_float2(v1.x, v1.y);
+        *reinterpret_cast<float2 *>(vb + kVPos + 64) = make_float2(v1.z, v1.w);
     };
 
     // ---- prologue ------------------------------------------------------------------------------------
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(kThreads, 2) void wino_conv_nhwc(WinoArgs args, con
     // loads in flight) publishes it.  V has three buffers so that the barrier may sit anywhere in the chunk
     // (WINO_BARRIER_SLOT; with it before the last slot the first operands of chunk c + 1 are fetched inside
     // chunk c -- measured slower than the barrier at the end, see the table at the top).
-    const int a_off = (wp * 8 * 32 + l31) * 4 + lhi * 2;
+    const int a_off = wp * 8 * kVPos + lhi * 64 + l31 * 2;
     float2 a0 = *reinterpret_cast<const float2 *>(Vs + a_off);
     float2 a1 = *reinterpret_cast<const float2 *>(Vs + a_off + kVPos);
     int vi = 0;                                // c % 3
