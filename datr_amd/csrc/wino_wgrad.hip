@@ -23,9 +23,11 @@
 // transform in registers and writes its 4 positions x 4 channels of both operands into the layout
 // [pos][row][8 tiles], in which an MFMA lane reads the four k-steps of a chunk with ONE ds_read_b128
 // (k-step j pairs the j-th tile of the lower half with the j-th of the upper).  LDS rows are channels
-// in the order row = 16 (c % 4) + c / 4, the two 4-tile halves of a row are swapped when bit 3 of the
-// row is set and the tiles of a half are rotated by xi: the b32 writes of a wave and the b128 reads
-// are bank-conflict free.  The partial sums keep that row order; the fold kernel undoes it.
+// in the order row = 16 (c % 4) + c / 4, the two 4-tile halves of a row are swapped when bit 3 XOR bit 2
+// of the row is set and the tiles of a half are rotated by xi: the b32 writes of a wave (32-lane groups,
+// 32 banks) and the b128 reads (16-lane groups, 64 banks) are bank-conflict free -- by the counters
+// (SQ_LDS_BANK_CONFLICT 0; with bit 3 alone the writes were two-way conflicts, 40 % of the LDS cycles,
+// at no measurable cost in time).  The partial sums keep that row order; the fold kernel undoes it.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -139,10 +141,12 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
         while (tx >= TW) { tx -= TW; if (++ty == TH) { ty = 0; ++tn; } }
     };
 
-    // LDS float index of (pos, row, tile): halves swapped on bit 3 of the row, tiles rotated inside their
+    // LDS float index of (pos, row, tile): halves swapped on bit 3 XOR bit 2 of the row (ds_write_b32 banks are
+    // (address / 4) mod 32 over 32-lane groups: with bit 3 alone rows q and q + 4 of a group shared a bank, 40 % of the
+    // kernel's LDS cycles were conflicts; the b128 reads stay conflict free in their 16-lane groups), tiles rotated inside their
     // half by the transform row xi (= fr for the writer): the four lanes of a quad then hit four banks,
     // and both operands of a position are rotated alike, so the MFMA's k pairing is unaffected
-    const int fslot = (((ft >> 2) ^ ((fq >> 3) & 1)) << 2) + ((ft + fr) & 3);
+    const int fslot = (((ft >> 2) ^ ((fq >> 3) & 1) ^ ((fq >> 2) & 1)) << 2) + ((ft + fr) & 3);
     // Packed arithmetic (v_pk_add_f32 / v_pk_fma_f32: two floats per instruction) on the float4s.
     struct P4 { f32x2 lo, hi; };
     auto pk = [](float4 v) { return P4{f32x2{v.x, v.y}, f32x2{v.z, v.w}}; };
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void wino_wgrad_nhwc(Args args, float *__
     // (not zero-initialised: the first chunk's first k-step multiplies onto the inline constant 0)
     f32x16 acc[PW][2][2];
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int rslot = (lhi ^ ((l31 >> 3) & 1)) << 2;
+    const int rslot = (lhi ^ ((l31 >> 3) & 1) ^ ((l31 >> 2) & 1)) << 2;
     auto multiply = [&](int buf, auto first) {
         float4 a[PW][2], b[PW][2];
 #pragma unroll
