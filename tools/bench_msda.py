@@ -39,8 +39,10 @@ def make_inputs(dev, Lq, dist, seed=3, N=2):
     if dist == "uniform":
         loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
     elif dist.startswith("gauss") and Lq == S:
-        # pixel-centre reference points + offsets ~ N(0, sigma px) in the target level
-        sigma = float(dist[5:] or 2.0)
+        # pixel-centre reference points + offsets ~ N(0, sigma px) in the target level; "gaussclip<sigma>": the same,
+        # clamped to +-4.6 px (every sample inside the windows of the clipped envelope: the plan's cost without misses)
+        clip = dist.startswith("gaussclip")
+        sigma = float(dist[9 if clip else 5:] or 2.0)
         refs = []
         for h, w in SHAPES:
             ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h,
@@ -48,7 +50,10 @@ def make_inputs(dev, Lq, dist, seed=3, N=2):
             refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
         ref = torch.cat(refs, 0).view(1, S, 1, 1, 1, 2)
         wh = torch.tensor([[w, h] for h, w in SHAPES], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
-        loc = (ref + torch.randn(N, Lq, M, L, P, 2, generator=g) * sigma / wh).contiguous()
+        off = torch.randn(N, Lq, M, L, P, 2, generator=g) * sigma
+        if clip:
+            off = off.clamp(-4.6, 4.6)
+        loc = (ref + off / wh).contiguous()
     else:
         # reference points: pixel centres of the pyramid (encoder) or uniform boxes (decoder)
         if Lq == S:
