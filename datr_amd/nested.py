@@ -47,6 +47,13 @@ class NestedTensor:
 
 def nested_tensor_from_tensor_list(tensor_list: Sequence[Tensor]) -> NestedTensor:
     """[C,H_i,W_i] images (or one [B,C,H,W] tensor) -> padded batch + mask."""
+    if isinstance(tensor_list, Tensor) and tensor_list.dim() == 4:
+        # one [B, C, H, W] batch: every image fills it, nothing to pad -- the batch itself with an all-False mask,
+        # in the memory format it came in (the reference copies image by image into a new contiguous tensor,
+        # util/misc.py:387-409: the same values; a channels_last slice of a training batch -- the teacher's input in
+        # engine.train_one_epoch_with_self_training -- would leave that copy in NCHW, off the NHWC kernels)
+        b, _, h, w = tensor_list.shape
+        return NestedTensor(tensor_list, torch.zeros((b, h, w), dtype=torch.bool, device=tensor_list.device), False)
     if isinstance(tensor_list, Tensor):
         tensor_list = list(tensor_list.unbind(0))
     if tensor_list[0].ndim != 3:

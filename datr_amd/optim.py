@@ -69,7 +69,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
     def _build(self):
         """(tables, key): device tables over every parameter that has a gradient, in group order."""
         piece = int(_native.lib.datr_adamw_piece_elements())
-        rows, pieces, key, dev = [], [], [], None
+        rows, pieces, key, dev, params = [], [], [], None, []
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
@@ -97,10 +97,11 @@ class FusedClipAdamW(torch.optim.Optimizer):
                 rows.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                              st["step"].data_ptr(), p.numel(), g["lr"], g["weight_decay"], ui, 0))
                 pieces += [(len(rows) - 1, off) for off in range(0, p.numel(), piece)]
-        return rows, pieces, dev
+                params.append(p)
+        return rows, pieces, dev, params
 
     def _tables_for_step(self):
-        rows, pieces, dev = self._build()
+        rows, pieces, dev, params = self._build()
         if not rows:
             return None
         key = tuple(rows)
@@ -124,6 +125,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
                 "partial": torch.empty(len(pieces), dtype=torch.float32, device=dev),
                 "norm_coef": torch.empty(2, dtype=torch.float32, device=dev),
             }
+        t["params"] = params
         return t
 
     # -- steps -------------------------------------------------------------------------------------
@@ -151,6 +153,11 @@ class FusedClipAdamW(torch.optim.Optimizer):
                                                  0 if used is None else used.data_ptr(), g0["betas"][0], g0["betas"][1],
                                                  g0["eps"], stream)
             _native.check(rc, "adamw_step")
+        # The kernel writes the parameters through raw pointers: autograd's version counters must move as they would
+        # under torch.optim's in-place ops, or caches keyed on (data_ptr, _version) -- the folded frozen-BN weights of
+        # pointwise.fold_frozen_bn that an eval-mode forward (engine.evaluate between epochs) reads -- keep serving
+        # the weights from before the step.
+        torch._C._increment_version(t["params"])
         self.last_norm = t["norm_coef"] if coef else None
         return self.last_norm
 

@@ -138,3 +138,42 @@ def test_evaluate_loop_on_device_matches_independent_protocol():
     want = bf.coco_stats([11, 12], gts, dts)
     assert np.allclose(coco, want, rtol=0, atol=1e-9), (coco, want)
     assert coco[1] > 0.3 and coco[8] > 0.3          # the loop's own detections find the planted boxes
+
+
+def test_eval_forward_after_own_optimizer_steps_sees_the_new_weights():
+    """An eval-mode forward caches the frozen-BN scales folded into the 1x1 convolution weights, keyed on
+    (data_ptr, _version) (pointwise.fold_frozen_bn).  The own AdamW and EMA kernels write parameters through raw
+    pointers, so they must move the version counters as torch.optim's in-place ops do -- or `evaluate()` after the
+    next epoch (engine.py:226-245 of the reference's main loop) silently runs on the weights of the previous one.
+    Eval forward (fills the cache), two training steps, eval forward again: the same as a deep copy's (fresh
+    pointers, nothing cached).  Also: a [B, C, H, W] tensor handed to the model keeps its memory format."""
+    import copy
+    from datr_amd import pointwise
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    from datr_amd.training import build_training, run_steps, synthetic_batch
+    dev = torch.device("cuda:0")
+    state = build_training(device=dev)
+    batch = synthetic_batch(1, 384, 512, 5, dev, seed=5)
+    images = batch[0].tensors
+    assert images.is_contiguous(memory_format=torch.channels_last)
+    nt = nested_tensor_from_tensor_list(images[1:])
+    assert nt.tensors.data_ptr() == images[1:].data_ptr() and nt.padded is False and not bool(nt.mask.any())
+    model = state.model
+
+    def eval_forward(m):
+        m.eval()
+        with torch.no_grad():
+            out = m(images)
+        m.train()
+        return out["pred_logits"].clone(), out["pred_boxes"].clone()
+    before = eval_forward(model)
+    assert len(pointwise._FROZEN_FOLDS) > 0                     # the cache is in play
+    w = next(p for n, p in model.named_parameters() if "layer3.0.conv1" in n)
+    v0, w0 = w._version, w.detach().clone()
+    run_steps(state, [batch, batch])
+    assert w._version > v0 and not torch.equal(w.detach(), w0)
+    after = eval_forward(model)
+    fresh = eval_forward(copy.deepcopy(model))
+    for a, b in zip(after, fresh):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    assert not torch.allclose(after[0], before[0], rtol=1e-4, atol=1e-5)   # the steps did change the outputs
