@@ -29,19 +29,30 @@ _workspaces = {}
 BACKEND = "library"
 BACKEND_REASON = "default"
 BIG_ROWS = 16384
+# Row counts (>= BIG_ROWS) for which the selections file holds entries, or None = do not look.  With the "library"
+# backend a large product whose row count is NOT among them goes to the own family: the selections are exact-shape
+# entries, a training run with multi-scale resizing (or the real C2F size, 87 040 tokens) sees other row counts every
+# batch, and there hipBLASLt's default heuristic runs the FFN products at 88-108 TF/s where the own kernels hold
+# ~125 whatever the shape (tools/probes and profiles/HISTORY.md, round 5).  DATR_GEMM_UNTUNED=library keeps them on
+# the library.
+TUNED_ROWS = None
 
 
-def set_backend(name: str, reason: str) -> None:
-    global BACKEND, BACKEND_REASON
+def set_backend(name: str, reason: str, tuned_rows=None) -> None:
+    global BACKEND, BACKEND_REASON, TUNED_ROWS
     assert name in ("library", "own")
     BACKEND, BACKEND_REASON = name, reason
+    TUNED_ROWS = None if tuned_rows is None else frozenset(tuned_rows)
 
 
 def own_big(*mats) -> bool:
-    """True when the large product over these row-major operands goes to the own family: backend "own", at
-    least BIG_ROWS rows in the first operand, every operand 2-d float32 on the device with a unit last stride,
+    """True when the large product over these row-major operands goes to the own family: backend "own" (or a row
+    count the library's selections do not cover, see TUNED_ROWS), at least BIG_ROWS rows in the first operand, every operand 2-d float32 on the device with a unit last stride,
     16-byte aligned rows and a feature count that is a multiple of 32 (what every kernel form accepts)."""
-    if BACKEND != "own" or mats[0].shape[0] < BIG_ROWS:
+    rows = mats[0].shape[0]
+    if rows < BIG_ROWS:
+        return False
+    if BACKEND != "own" and (TUNED_ROWS is None or rows in TUNED_ROWS):
         return False
     for t in mats:
         if not (t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and t.shape[1] % 32 == 0

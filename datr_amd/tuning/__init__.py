@@ -73,11 +73,32 @@ def enable(path: str = None, tune: bool = False) -> bool:
     if forced == "own":
         gemm.set_backend("own", "DATR_GEMM_BACKEND=own")
     elif forced == "library" or ok:
-        gemm.set_backend("library", "hipBLASLt, per-shape selections of datr_amd/tuning" if ok
-                         else "DATR_GEMM_BACKEND=library: hipBLASLt default heuristic")
+        # row counts the selections cover: large products with another row count go to the own family (gemm.TUNED_ROWS)
+        rows = None
+        if ok and forced != "library" and not tune and os.environ.get("DATR_GEMM_UNTUNED", "own") != "library":
+            rows = tuned_row_counts(path, gemm.BIG_ROWS)
+        gemm.set_backend("library", "hipBLASLt, per-shape selections of datr_amd/tuning"
+                         + ("; own GEMM family for large products of other row counts" if rows is not None else "") if ok
+                         else "DATR_GEMM_BACKEND=library: hipBLASLt default heuristic", rows)
     else:
         gemm.set_backend("own", "tuning file missing or not valid for this torch / hipBLASLt: own GEMM family")
     return ok
+
+
+def tuned_row_counts(path: str, at_least: int):
+    """Every GEMM dimension >= at_least that appears in the selections file (entries `op,tn_m_n_k_ld_...,solution,ms`):
+    the token / pixel counts the selections were recorded for."""
+    rows = set()
+    try:
+        for line in open(path):
+            p = line.split(",")
+            if len(p) < 4 or p[0] == "Validator":
+                continue
+            dims = p[1].split("_ld_")[0].split("_")[1:4]
+            rows.update(int(d) for d in dims if d.isdigit() and int(d) >= at_least)
+    except OSError:
+        return None
+    return rows
 
 
 def _enable(path: str, tune: bool) -> bool:

@@ -138,8 +138,16 @@ def test_fast_linear_matches_autograd(rows, cin, cout):
     yr = torch.nn.functional.linear(x, lin.weight, lin.bias)
     yr.backward(go)
     ref = [yr.detach(), x.grad, lin.weight.grad, lin.bias.grad]
-    for a, b in zip(got[:2], ref[:2]):
-        assert torch.equal(a, b)                                     # the same GEMM calls
+    from datr_amd import gemm
+    if gemm.own_big(x.detach().reshape(-1, cin), lin.weight):
+        # a row count the library's selections do not cover (or the "own" backend): forward and data gradient are the
+        # own NT / NN forms -- the same products in another fp32 summation order
+        for a, e in ((got[0], torch.nn.functional.linear(x.detach().double(), lin.weight.double(), lin.bias.double())),
+                     (got[1], go.double() @ lin.weight.double())):
+            assert float((a.double() - e).abs().max()) <= 4e-6 * float(e.abs().max())
+    else:
+        for a, b in zip(got[:2], ref[:2]):
+            assert torch.equal(a, b)                                 # the same GEMM calls
     exact_w = (go.reshape(-1, cout).double().t() @ x.detach().reshape(-1, cin).double())
     wscale = float(exact_w.abs().max())
     assert float((got[2].double() - exact_w).abs().max()) <= max(5e-6 * wscale, float((ref[2].double() - exact_w).abs().max()) * 2)

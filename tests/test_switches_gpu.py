@@ -47,6 +47,7 @@ GROUPS = {
                         "DATR_OWN_CONV3X3_MAX_CH": "64"},
     "own-gemm-backend": {"DATR_GEMM_BACKEND": "own", "DATR_OWN_BOTTLENECK_MIN_PIXELS": "1", "DATR_FREEZE_GC": "0"},
     "library-gemm-default-heuristic": {"DATR_GEMM_BACKEND": "library", "DATR_TUNING_FILE": "/nonexistent.csv"},
+    "untuned-rows-on-the-library": {"DATR_GEMM_UNTUNED": "library"},
     "split-bf16-experiment": {"DATR_GEMM_SPLIT_BF16": "1"},
     "nchw-backbone": {"__channels_last": "False"},
     "one-rank-collectives": {"DATR_DIST_FORCE_COLLECTIVES": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"},
