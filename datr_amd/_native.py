@@ -173,6 +173,14 @@ def check(code: int, what: str) -> None:
         raise RuntimeError(f"{what}: {lib.datr_strerror(code).decode()} (code {code})")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream_ptr(device: torch.device) -> int:
-    """hipStream_t of torch's current stream on `device`, as an integer for ctypes."""
+    """hipStream_t of torch's current stream on `device`, as an integer for ctypes.  Through torch's raw-stream
+    accessor where it exists (0.3 us; `torch.cuda.current_stream(device).cuda_stream` builds a Stream object per call,
+    5 us, ~220 times per training step)."""
+    if _RAW_STREAM is not None:
+        idx = device.index
+        return _RAW_STREAM(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream

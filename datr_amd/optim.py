@@ -48,6 +48,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
         if len(b) != 1:
             raise ValueError("FusedClipAdamW: betas / eps must be the same in every parameter group")
         self._tables = None
+        self._static = {}           # id(param) -> addresses / strides validated once (_static_of)
         self._index = None          # id(param) -> position in all_params order (the `used` flags' order)
         self.last_norm = None       # device tensor [2]: gradient norm, clip coefficient of the last clip_and_step
 
@@ -65,45 +66,93 @@ class FusedClipAdamW(torch.optim.Optimizer):
     def set_used_order(self, params):
         """The parameter order the `used` flags of clip_and_step refer to."""
         self._index = {id(p): i for i, p in enumerate(params)}
+        self._tables = None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = None                     # the moments are other tensors now
+        self._static = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = None
+        self._static = {}
+
+    def _static_of(self, p):
+        """What does not change from step to step for a parameter, validated ONCE (the layout checks of every
+        parameter, every step, were 3.6 ms of host time): addresses of the parameter and its moments, element count,
+        strides.  Dropped by load_state_dict / add_param_group / a parameter that moved."""
+        hit = self._static.get(id(p))
+        if hit is not None and hit[0] == p.data_ptr():
+            return hit
+        if not (p.is_cuda and p.dtype == torch.float32):
+            raise TypeError("FusedClipAdamW: float32 device parameters only")
+        if not _dense(p):
+            raise ValueError("FusedClipAdamW: parameters must be dense")
+        st = self._state_of(p)
+        for k in ("exp_avg", "exp_avg_sq"):       # moments of a loaded state_dict may carry another layout
+            if not _same_layout(st[k], p):
+                st[k] = torch.empty_like(p).copy_(st[k])
+        hit = self._static[id(p)] = (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                     st["step"].data_ptr(), p.numel(), p.stride(), p.shape)
+        return hit
 
     def _build(self):
         """(tables, key): device tables over every parameter that has a gradient, in group order."""
         piece = int(_native.lib.datr_adamw_piece_elements())
-        rows, pieces, key, dev, params = [], [], [], None, []
+        rows, pieces, dev, params = [], [], None, []
+        index = self._index
         for g in self.param_groups:
+            lr, wd = g["lr"], g["weight_decay"]
             for p in g["params"]:
-                if p.grad is None:
-                    continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
-                    raise TypeError("FusedClipAdamW: float32 device parameters only")
-                st = self._state_of(p)
                 gr = p.grad
-                if not _dense(p):
-                    raise ValueError("FusedClipAdamW: parameters must be dense")
-                if not _same_layout(gr, p):           # e.g. an NCHW gradient of a channels_last weight: re-lay it out
+                if gr is None:
+                    continue
+                pptr, m1, m2, stp, numel, strides, shape = self._static_of(p)
+                if gr.dtype != torch.float32:
+                    raise TypeError("FusedClipAdamW: float32 device parameters only")
+                if gr.stride() != strides and not _same_layout(gr, p):   # e.g. an NCHW gradient of a channels_last weight
                     gr = p.grad = torch.empty_like(p).copy_(gr)
-                for k in ("exp_avg", "exp_avg_sq"):   # moments of a loaded state_dict may carry another layout
-                    if not _same_layout(st[k], p):
-                        st[k] = torch.empty_like(p).copy_(st[k])
                 dev = p.device
                 # -1 = no used flag for this tensor (the kernel then always updates it); once an order is set a
                 # parameter missing from it would silently follow another parameter's flag: refuse
                 ui = -1
-                if self._index is not None:
-                    if id(p) not in self._index:
+                if index is not None:
+                    ui = index.get(id(p), -2)
+                    if ui == -2:
                         raise KeyError("FusedClipAdamW: a parameter with a gradient is missing from the "
                                        "set_used_order() list")
-                    ui = self._index[id(p)]
-                rows.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                             st["step"].data_ptr(), p.numel(), g["lr"], g["weight_decay"], ui, 0))
-                pieces += [(len(rows) - 1, off) for off in range(0, p.numel(), piece)]
+                rows.append((pptr, gr.data_ptr(), m1, m2, stp, numel, lr, wd, ui, 0))
+                n = len(rows) - 1
+                if numel <= piece:
+                    pieces.append((n, 0))
+                else:
+                    pieces += [(n, off) for off in range(0, numel, piece)]
                 params.append(p)
         return rows, pieces, dev, params
 
+    def _signature(self):
+        """What the device tables depend on, cheaply: learning rate / weight decay of every group and the addresses of
+        every parameter and gradient.  Unchanged (the flat-bucket reducer's views, or the caching allocator handing
+        the same blocks out every step): the tables of the last step are reused and the per-parameter checks of
+        _build -- 4 ms of host time per step, on the critical path where the host is the bound (small images,
+        several ranks per host) -- are skipped."""
+        sig = []
+        for g in self.param_groups:
+            sig.append((g["lr"], g["weight_decay"], g["betas"], g["eps"]))
+            for p in g["params"]:
+                gr = p.grad
+                sig.append((p.data_ptr(), 0 if gr is None else gr.data_ptr()))
+        return tuple(sig)
+
     def _tables_for_step(self):
+        sig = self._signature()
+        if self._tables is not None and self._tables.get("sig") == sig:
+            return self._tables
         rows, pieces, dev, params = self._build()
         if not rows:
             return None
+        sig = self._signature()                       # (_build may have re-laid a gradient out)
         key = tuple(rows)
         t = self._tables
         if t is None or t["key"] != key:
@@ -126,6 +175,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
                 "norm_coef": torch.empty(2, dtype=torch.float32, device=dev),
             }
         t["params"] = params
+        t["sig"] = sig
         return t
 
     # -- steps -------------------------------------------------------------------------------------
