@@ -173,6 +173,31 @@ def check(code: int, what: str) -> None:
         raise RuntimeError(f"{what}: {lib.datr_strerror(code).decode()} (code {code})")
 
 
+class _NoGuard:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """`with on_device(t.device):` around a native launch -- `torch.cuda.device(device)` when `device` is not the
+    process' current one, nothing otherwise (one rank per GPU: the current device IS the tensors' device, and the
+    context manager's two device switches per launch, ~800 launches per training step, were host time)."""
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 

@@ -59,7 +59,7 @@ def _relu_gate(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     from .pointwise import _ones
     C = dy.shape[1]
     dz = torch.empty_like(dy, memory_format=torch.channels_last)
-    with torch.cuda.device(dy.device):
+    with _native.on_device(dy.device):
         rc = _native.lib.datr_affine_act_backward_f32(dy.data_ptr(), y.data_ptr(), _ones(C, dy.device).data_ptr(),
                                                       dy.numel(), C, 1, 1, dz.data_ptr(), 0,
                                                       _native.current_stream_ptr(dy.device))
@@ -97,7 +97,7 @@ class _BottleneckFn(Function):
             stream = _native.current_stream_ptr(x.device)
             y2 = torch.empty((N, Cm, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
             ws = _workspace(y1.shape, Cm, x.device)
-            with torch.cuda.device(x.device):
+            with _native.on_device(x.device):
                 rc = _native.lib.datr_conv3x3s2_weights_f32(w2.data_ptr(), Cm, Cm, sw[0], sw[1], sw[2], sw[3], wt.data_ptr(),
                                                             0 if wt_t is None else wt_t.data_ptr(), stream)
                 _native.check(rc, "conv3x3s2_weights")
@@ -151,7 +151,7 @@ class _BottleneckFn(Function):
             stream = _native.current_stream_ptr(dy.device)
             ws = _workspace(y1.shape, Cm, dy.device)
             d1 = torch.empty_like(y1, memory_format=torch.channels_last)
-            with torch.cuda.device(dy.device):
+            with _native.on_device(dy.device):
                 rc = _native.lib.datr_conv3x3s2_dgrad_nhwc_f32(dz2.data_ptr(), wt_t.data_ptr(), N, H, W, Cm, Cm,
                                                                d1.data_ptr(), ws.data_ptr(), ws.numel(), stream)
                 _native.check(rc, "conv3x3s2_dgrad")
@@ -177,7 +177,7 @@ class _BottleneckFn(Function):
                 dxs = gemm.gemm_nn(dz3r, wds)
                 if ctx.stride == 2:
                     full = torch.empty_like(x, memory_format=torch.channels_last)
-                    with torch.cuda.device(dy.device):
+                    with _native.on_device(dy.device):
                         rc = _native.lib.datr_even_pixels_scatter_nhwc_f32(dxs.data_ptr(), N, H, W, Cin, full.data_ptr(),
                                                                            _native.current_stream_ptr(dy.device))
                     _native.check(rc, "even_pixels_scatter")

@@ -106,7 +106,7 @@ class _ContrastLoss(torch.autograd.Function):
         K, C = q_s.shape
         loss = torch.empty(1, device=q_s.device, dtype=torch.float32)
         dq_s, dq_t = torch.empty_like(q_s), torch.empty_like(q_t)
-        with torch.cuda.device(q_s.device):
+        with _native.on_device(q_s.device):
             rc = _native.lib.datr_contrast_loss_f32(q_s.data_ptr(), q_t.data_ptr(), g.data_ptr(), m_s.data_ptr(),
                                                     m_t.data_ptr(), K, C, 1e-12, loss.data_ptr(), dq_s.data_ptr(),
                                                     dq_t.data_ptr(), _native.current_stream_ptr(q_s.device))

@@ -37,7 +37,7 @@ def classifier_forward(acts, weight, bias):
     n = acts[0].shape[0]
     outs = [torch.empty((n, 1, a.shape[2], a.shape[3]), dtype=a.dtype, device=a.device) for a in acts]
     w = weight.contiguous()
-    with torch.cuda.device(acts[0].device):
+    with _native.on_device(acts[0].device):
         levels = _c1_levels(acts, outs)
         rc = _native.lib.datr_conv3x3_cout1_forward_f32(ctypes.addressof(levels), len(acts), n, acts[0].shape[1],
                                                         w.data_ptr(), 0 if bias is None else bias.data_ptr(),
@@ -58,7 +58,7 @@ def classifier_backward(acts, douts, weight, slope):
     levels = _c1_levels(acts, douts, dzs)
     floats = int(_native.lib.datr_conv3x3_cout1_partial_floats(ctypes.addressof(levels), len(acts), n))
     partial = torch.empty(max(floats, 1), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _native.on_device(w.device):
         rc = _native.lib.datr_conv3x3_cout1_backward_f32(ctypes.addressof(levels), len(acts), n, acts[0].shape[1], w.data_ptr(),
                                                          ctypes.c_float(slope), dw.data_ptr(), db.data_ptr(),
                                                          partial.data_ptr(), _native.current_stream_ptr(w.device))
@@ -223,7 +223,7 @@ class _ClassPrototypes(torch.autograd.Function):
         new_global = torch.empty(K, C, device=dev, dtype=torch.float32)
         new_amount = torch.empty(K, device=dev, dtype=torch.float32)
         onehot = torch.empty(R, K, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _native.on_device(dev):
             rc = _native.lib.datr_class_prototypes_forward_f32(
                 feats.data_ptr(), labels.data_ptr(), global_proto.data_ptr(), amount.data_ptr(), R, C, K,
                 proto.data_ptr(), present.data_ptr(), new_global.data_ptr(), new_amount.data_ptr(), onehot.data_ptr(),
@@ -242,7 +242,7 @@ class _ClassPrototypes(torch.autograd.Function):
         R, C, K = ctx.shape
         d_proto = d_proto.contiguous()
         d_feats = torch.empty(R, C, device=d_proto.device, dtype=torch.float32)
-        with torch.cuda.device(d_proto.device):
+        with _native.on_device(d_proto.device):
             rc = _native.lib.datr_class_prototypes_backward_f32(d_proto.data_ptr(), labels.data_ptr(), count.data_ptr(),
                                                                 R, C, K, d_feats.data_ptr(),
                                                                 _native.current_stream_ptr(d_proto.device))

@@ -52,7 +52,7 @@ class _DevicePlan:
 
     def run(self, d: float):
         from . import _native
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             rc = _native.lib.datr_ema_update_f32(self.tensors.data_ptr(), self.pieces.data_ptr(), self.npieces,
                                                  float(d), _native.current_stream_ptr(self.device))
         _native.check(rc, "ema_update")

@@ -19,7 +19,7 @@ def _focal_forward(logits, target, alpha, gamma):
     sums = torch.empty(G, dtype=torch.float32, device=logits.device)
     scratch = torch.empty(max(int(_native.lib.datr_focal_scratch_floats(G, R)), 1),
                           dtype=torch.float32, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with _native.on_device(logits.device):
         rc = _native.lib.datr_focal_loss_forward_f32(
             logits.data_ptr(), target.data_ptr(), G, R, C, alpha, gamma, scratch.data_ptr(),
             sums.data_ptr(), _native.current_stream_ptr(logits.device))
@@ -30,7 +30,7 @@ def _focal_forward(logits, target, alpha, gamma):
 def _focal_backward(logits, target, grad_sums, alpha, gamma):
     G, R, C = logits.shape
     grad = torch.empty_like(logits)
-    with torch.cuda.device(logits.device):
+    with _native.on_device(logits.device):
         rc = _native.lib.datr_focal_loss_backward_f32(
             logits.data_ptr(), target.data_ptr(), grad_sums.data_ptr(), G, R, C, alpha, gamma,
             grad.data_ptr(), _native.current_stream_ptr(logits.device))
@@ -81,7 +81,7 @@ class _BoxLossSums(Function):
     def forward(ctx, src, tgt, group, G):
         src, tgt, group = src.contiguous(), tgt.contiguous(), group.contiguous()
         sums = torch.empty(4, G, dtype=torch.float32, device=src.device)
-        with torch.cuda.device(src.device):
+        with _native.on_device(src.device):
             rc = _native.lib.datr_box_loss_forward_f32(
                 src.data_ptr(), tgt.data_ptr(), group.data_ptr(), src.shape[0], G, sums.data_ptr(),
                 _native.current_stream_ptr(src.device))
@@ -95,7 +95,7 @@ class _BoxLossSums(Function):
         src, tgt, group = ctx.saved_tensors
         g = grad_sums.contiguous().float()
         d_src = torch.empty_like(src)
-        with torch.cuda.device(src.device):
+        with _native.on_device(src.device):
             rc = _native.lib.datr_box_loss_backward_f32(
                 src.data_ptr(), tgt.data_ptr(), group.data_ptr(), g[0].data_ptr(), g[1].data_ptr(),
                 src.shape[0], d_src.data_ptr(), _native.current_stream_ptr(src.device))

@@ -33,7 +33,7 @@ class _AffineAct(Function):
         if res is not None:
             res = res.contiguous(memory_format=fmt)
         inner = 1 if nhwc else H * W
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_affine_act_forward_f32(
                 x.data_ptr(), 0 if res is None else res.data_ptr(), scale.data_ptr(),
                 shift.data_ptr(), x.numel(), C, inner, int(relu), y.data_ptr(),
@@ -63,7 +63,7 @@ class _AffineAct(Function):
         dx = torch.empty_like(dy, memory_format=fmt)
         dres = (torch.empty_like(dy, memory_format=fmt)
                 if ctx.has_res and ctx.needs_input_grad[3] else None)
-        with torch.cuda.device(dy.device):
+        with _native.on_device(dy.device):
             if dy2 is None:
                 rc = _native.lib.datr_affine_act_backward_f32(
                     dy.data_ptr(), 0 if y is None else y.data_ptr(), scale.data_ptr(), dy.numel(), C,
@@ -110,7 +110,7 @@ class _GroupNormNHWC(Function):
         rstd = torch.empty_like(mean)
         part = torch.empty(int(_native.lib.datr_groupnorm_partial_floats(N, H * W, C, groups)), device=x.device,
                            dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_groupnorm_nhwc_forward_f32(
                 x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, H * W, C, groups, eps, y.data_ptr(),
                 mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), _native.current_stream_ptr(x.device))
@@ -130,7 +130,7 @@ class _GroupNormNHWC(Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         part = torch.empty(int(_native.lib.datr_groupnorm_partial_floats(N, H * W, C, ctx.groups)),
                            device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_groupnorm_nhwc_backward_f32(
                 dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, H * W, C,
                 ctx.groups, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), part.data_ptr(),
@@ -176,7 +176,7 @@ def _ffn_hidden_gradient(dy2: torch.Tensor, w2: torch.Tensor, h: torch.Tensor):
     db1 = torch.empty(cols, device=dh.device, dtype=dh.dtype)
     nblk = int(_native.lib.datr_relu_bwd_bias_partial_rows(rows))
     partial = torch.empty(nblk * cols, device=dh.device, dtype=dh.dtype)
-    with torch.cuda.device(dh.device):
+    with _native.on_device(dh.device):
         rc = _native.lib.datr_relu_bwd_bias_f32(dh.data_ptr(), h.data_ptr(), rows, cols, partial.data_ptr(),
                                                 db1.data_ptr(), _native.current_stream_ptr(dh.device))
     _native.check(rc, "relu_bwd_bias")
@@ -317,7 +317,7 @@ class _AddLayerNorm(Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_add_layernorm_forward_f32(
                 x2.data_ptr(), 0 if r2 is None else r2.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                 rows, C, float(eps), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
@@ -341,7 +341,7 @@ class _AddLayerNorm(Function):
         dbeta = torch.empty_like(gamma)
         partial = torch.empty(int(_native.lib.datr_add_layernorm_partial_floats(rows)),
                               device=x2.device, dtype=torch.float32)
-        with torch.cuda.device(x2.device):
+        with _native.on_device(x2.device):
             rc = _native.lib.datr_add_layernorm_backward_f32(
                 dy2.data_ptr(), x2.data_ptr(), 0 if r2 is None else r2.data_ptr(), mean.data_ptr(),
                 rstd.data_ptr(), gamma.data_ptr(), rows, C, dx.data_ptr(), partial.data_ptr(),
@@ -376,7 +376,7 @@ class _FFNAddNorm(Function):
         ctx.shape = shape
         ctx.query = pos is not None
         if pos is None:
-            with torch.cuda.device(x.device):
+            with _native.on_device(x.device):
                 rc = _native.lib.datr_add_layernorm_forward_f32(
                     y.data_ptr(), x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, float(eps),
                     out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _native.current_stream_ptr(x.device))
@@ -388,7 +388,7 @@ class _FFNAddNorm(Function):
         p2 = pos.reshape(-1, C)
         p2 = p2 if p2.is_contiguous() else p2.contiguous()
         outq = torch.empty_like(x2)
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_add_layernorm_forward_query_f32(
                 y.data_ptr(), x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), p2.data_ptr(), rows, C, float(eps),
                 out.data_ptr(), outq.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _native.current_stream_ptr(x.device))
@@ -424,7 +424,7 @@ class _FFNAddNorm(Function):
         partial = torch.empty(int(_native.lib.datr_add_layernorm_partial_floats(rows)),
                               device=x2.device, dtype=torch.float32)
         stream = _native.current_stream_ptr(x2.device)
-        with torch.cuda.device(x2.device):
+        with _native.on_device(x2.device):
             # ... which fall out of the LayerNorm backward's own pass over dsum (no column-sum launches)
             if len(live) == 1:
                 rc = _native.lib.datr_add_layernorm_backward_colsum_f32(
@@ -541,7 +541,7 @@ def topk_rows(scores: torch.Tensor, k: int):
     rows, n = x.shape
     idx = torch.empty(rows, k, dtype=torch.int64, device=x.device)
     val = torch.empty(rows, k, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _native.on_device(x.device):
         rc = _native.lib.datr_topk_rows_f32(x.data_ptr(), rows, n, k, idx.data_ptr(), val.data_ptr(),
                                             _native.current_stream_ptr(x.device))
     _native.check(rc, "topk_rows")
@@ -556,7 +556,7 @@ class _RefineBoxes(Function):
     def forward(ctx, delta, ref, eps):
         d, r = delta.contiguous(), ref.contiguous()
         out = torch.empty_like(d)
-        with torch.cuda.device(d.device):
+        with _native.on_device(d.device):
             rc = _native.lib.datr_refine_boxes_forward_f32(d.data_ptr(), r.data_ptr(), d.numel(), eps, out.data_ptr(),
                                                            _native.current_stream_ptr(d.device))
         _native.check(rc, "refine_boxes_forward")
@@ -574,7 +574,7 @@ class _RefineBoxes(Function):
         dr = torch.empty_like(out) if ctx.needs_input_grad[1] else None
         if dd is None and dr is None:
             return None, None, None
-        with torch.cuda.device(g.device):
+        with _native.on_device(g.device):
             rc = _native.lib.datr_refine_boxes_backward_f32(g.data_ptr(), out.data_ptr(), r.data_ptr(), g.numel(), ctx.eps,
                                                             0 if dd is None else dd.data_ptr(),
                                                             0 if dr is None else dr.data_ptr(),
@@ -627,7 +627,7 @@ class _FanOut(torch.autograd.Function):
             ref = live[0]
             out = torch.empty_like(ref)
         ptrs = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
-        with torch.cuda.device(ref.device):
+        with _native.on_device(ref.device):
             rc = _native.lib.datr_add_n_f32(ctypes.addressof(ptrs), len(live), ref.numel(), out.data_ptr(),
                                             _native.current_stream_ptr(ref.device))
         _native.check(rc, "add_n")
@@ -649,7 +649,7 @@ def column_sums(x2: torch.Tensor) -> torch.Tensor:
     out = torch.empty(cols, device=x2.device, dtype=x2.dtype)
     nblk = int(_native.lib.datr_relu_bwd_bias_partial_rows(rows))
     partial = torch.empty(nblk * cols, device=x2.device, dtype=x2.dtype)
-    with torch.cuda.device(x2.device):
+    with _native.on_device(x2.device):
         rc = _native.lib.datr_colsum_f32(x2.data_ptr(), rows, cols, partial.data_ptr(), out.data_ptr(),
                                          _native.current_stream_ptr(x2.device))
     _native.check(rc, "colsum")
@@ -735,7 +735,7 @@ class _LinearReluFn(Function):
             dy2 = dy2.contiguous()
         dz = torch.empty_like(dy2)
         from .pointwise import _ones
-        with torch.cuda.device(dy2.device):
+        with _native.on_device(dy2.device):
             rc = _native.lib.datr_affine_act_backward_f32(dy2.data_ptr(), y.data_ptr(), _ones(cols, dy2.device).data_ptr(),
                                                           dy2.numel(), cols, 1, 1, dz.data_ptr(), 0,
                                                           _native.current_stream_ptr(dy2.device))
@@ -807,7 +807,7 @@ class _AttentionD32(Function):
         lse = torch.empty(N, heads, L, device=q.device, dtype=torch.float32)
         strides = (ctypes.c_int64 * 8)(q.stride(0), q.stride(1), k.stride(0), k.stride(1),
                                        v.stride(0), v.stride(1), out.stride(0), out.stride(1))
-        with torch.cuda.device(q.device):
+        with _native.on_device(q.device):
             rc = _native.lib.datr_mha_forward_d32_f32(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), 0 if mask is None else mask.data_ptr(), L, N,
                 heads, ctypes.addressof(strides), 32 ** -0.5, out.data_ptr(), lse.data_ptr(),
@@ -835,7 +835,7 @@ class _AttentionD32(Function):
                                         v.stride(0), v.stride(1), out.stride(0), out.stride(1),
                                         dout.stride(0), dout.stride(1), dq.stride(0), dq.stride(1),
                                         dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1))
-        with torch.cuda.device(q.device):
+        with _native.on_device(q.device):
             rc = _native.lib.datr_mha_backward_d32_f32(
                 dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
                 0 if mask is None else mask.data_ptr(), L, N, H, ctypes.addressof(strides), 32 ** -0.5,
@@ -866,7 +866,7 @@ class _AttentionQKD32(Function):
         lse = torch.empty(N, heads, L, device=qk.device, dtype=torch.float32)
         strides = (ctypes.c_int64 * 8)(qk.stride(0), qk.stride(1), qk.stride(0), qk.stride(1),
                                        v.stride(0), v.stride(1), out.stride(0), out.stride(1))
-        with torch.cuda.device(qk.device):
+        with _native.on_device(qk.device):
             rc = _native.lib.datr_mha_forward_d32_f32(
                 qk.data_ptr(), qk.data_ptr() + 4 * E, v.data_ptr(), 0 if mask is None else mask.data_ptr(), L, N,
                 heads, ctypes.addressof(strides), 32 ** -0.5, out.data_ptr(), lse.data_ptr(),
@@ -892,7 +892,7 @@ class _AttentionQKD32(Function):
                                         v.stride(0), v.stride(1), out.stride(0), out.stride(1),
                                         dout.stride(0), dout.stride(1), dqk.stride(0), dqk.stride(1),
                                         dqk.stride(0), dqk.stride(1), dv.stride(0), dv.stride(1))
-        with torch.cuda.device(qk.device):
+        with _native.on_device(qk.device):
             rc = _native.lib.datr_mha_backward_d32_f32(
                 dout.data_ptr(), qk.data_ptr(), qk.data_ptr() + 4 * E, v.data_ptr(), out.data_ptr(), lse.data_ptr(),
                 0 if mask is None else mask.data_ptr(), L, N, H, ctypes.addressof(strides), 32 ** -0.5,

@@ -108,7 +108,7 @@ def _run(form, A, B, M, N, K, out, scale, shift, residual, gate, relu, colsum, r
     if form == TN and scale is not None:
         need = max(need, M * N)
     ws = _workspace(dev, stream, need)
-    with torch.cuda.device(dev):
+    with _native.on_device(dev):
         rc = _native.lib.datr_gemm_f32(form, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), M, N, K,
                                        ctypes.addressof(epi), out.data_ptr(), _ld(out),
                                        0 if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), stream)

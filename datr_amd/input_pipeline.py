@@ -52,7 +52,7 @@ def collate_uint8_on_device(images: Sequence[torch.Tensor], device=None, mean=IM
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
     slot = 3 * Hp * Wp * 4
-    with torch.cuda.device(device):
+    with _native.on_device(device):
         stream = _native.current_stream_ptr(device)
         for i, im in enumerate(images):
             d = im.to(device, non_blocking=True).contiguous()
@@ -149,7 +149,7 @@ def resize_uint8_on_device(image: torch.Tensor, size_hw, flip: bool = False) -> 
     xb, xk, ksx = _device_coeffs(W, ow, image.device) if ow != W else (None, None, 0)
     yb, yk, ksy = _device_coeffs(H, oh, image.device) if oh != H else (None, None, 0)
     ptr = lambda t: 0 if t is None else t.data_ptr()
-    with torch.cuda.device(image.device):
+    with _native.on_device(image.device):
         rc = _native.lib.datr_resize_bilinear_u8(src.data_ptr(), H, W, int(bool(flip)), ptr(xb), ptr(xk), ksx,
                                                  ptr(yb), ptr(yk), ksy, oh, ow, tmp.data_ptr(), dst.data_ptr(),
                                                  _native.current_stream_ptr(image.device))

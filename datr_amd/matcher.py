@@ -72,7 +72,7 @@ def solve_lsap_device(C: torch.Tensor, sizes, transposed: bool = False):
         return q_idx, t_idx, status
     Ct = C.contiguous() if transposed else C.transpose(-1, -2).contiguous()
     offsets = _device_offsets(sizes, dev)
-    with torch.cuda.device(dev):
+    with _native.on_device(dev):
         rc = _native.lib.datr_lsap_f32(Ct.data_ptr(), offsets.data_ptr(), G, B, Tsum, nq,
                                        max(sizes), q_idx.data_ptr(), t_idx.data_ptr(),
                                        status.data_ptr(), _native.current_stream_ptr(dev))
@@ -144,7 +144,7 @@ class HungarianMatcher(nn.Module):
         logits, boxes = logits.float().contiguous(), boxes.float().contiguous()
         cost_t = torch.empty(sets, T, nq, dtype=torch.float32, device=logits.device)
         ok = torch.ones(1, dtype=torch.int32, device=logits.device)
-        with torch.cuda.device(logits.device):
+        with _native.on_device(logits.device):
             rc = _native.lib.datr_match_cost_f32(
                 logits.data_ptr(), boxes.data_ptr(), tgt_ids.data_ptr(), tgt_bbox.data_ptr(), sets, nq,
                 T, C, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou),

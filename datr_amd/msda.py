@@ -134,7 +134,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         envelope = np.ascontiguousarray(envelope, dtype=np.float32)
         if envelope.shape != (8, 4, 4):
             raise ValueError(f"offset envelope must be [8, 4, 4], got {envelope.shape}")
-    with torch.cuda.device(value.device):
+    with _native.on_device(value.device):
         stream = _native.current_stream_ptr(value.device)
         if sfx == "f32" and D == 32 and Lq == S and L == 4 and P == 4 and PYR_FORWARD and route == 0:
             # encoder self-attention: pyramid-region forward, coarse-level windows staged in LDS
@@ -174,7 +174,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             and tuple(grad_value_out.shape) == (N, S, M, D) and grad_value_out.stride(3) == 1 \
             and grad_value_out.stride(2) == D and grad_value_out.stride(0) == S * grad_value_out.stride(1):
         sh_host, ls_host = _host_meta(shapes, lsi)
-        with torch.cuda.device(value.device):
+        with _native.on_device(value.device):
             rc = _native.lib.datr_msda_backward_strided_f32(
                 grad_output.data_ptr(), value.data_ptr(), sh_host.ctypes.data, ls_host.ctypes.data,
                 sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, grad_value_out.data_ptr(),
@@ -184,7 +184,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             _native.check(rc, "ms_deform_attn_backward (strided)")
             return [grad_value_out, grad_loc, grad_attn]
     grad_value = torch.empty_like(value)            # zero-filled by the library on the stream
-    with torch.cuda.device(value.device):
+    with _native.on_device(value.device):
         stream = _native.current_stream_ptr(value.device)
         if sfx == "f32" and D == 32 and Lq >= TILED_BACKWARD_MIN_LQ and route < 2:
             # geometry-dispatched backward (pyramid regions / owner-computes / query tiles): needs
@@ -242,7 +242,7 @@ def ms_deform_attn_backward_query_grad(value, spatial_shapes, level_start_index,
         assert env.shape == (8, 4, 4)
     grad_value = torch.empty_like(value)            # zero-filled by the library on the stream
     grad_query = torch.empty((N, Lq, M * 48), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device):
+    with _native.on_device(value.device):
         rc = _native.lib.datr_msda_backward_pyramid_query_f32(
             grad_output.data_ptr(), value.data_ptr(), sh_host.ctypes.data, ls_host.ctypes.data,
             0 if env is None else env.ctypes.data, sampling_loc.data_ptr(), attn_weight.data_ptr(),
@@ -419,7 +419,7 @@ def _prologue_forward(both, ref):
     rows = both.numel() // 384
     loc = torch.empty(*both.shape[:-1], 8, 4, 4, 2, device=both.device, dtype=torch.float32)
     attn = torch.empty(*both.shape[:-1], 8, 4, 4, device=both.device, dtype=torch.float32)
-    with torch.cuda.device(both.device):
+    with _native.on_device(both.device):
         rc = _native.lib.datr_msda_prologue_forward_f32(
             both.data_ptr(), ref.data_ptr(), rows, ref.shape[-1], loc.data_ptr(), attn.data_ptr(),
             _native.current_stream_ptr(both.device))
@@ -432,7 +432,7 @@ def _prologue_backward(d_loc, d_attn, attn, ref, shape):
         if d_loc is None else d_loc.contiguous()
     d_attn = torch.zeros_like(attn) if d_attn is None else d_attn.contiguous()
     d_both = torch.empty(shape, device=attn.device, dtype=torch.float32)
-    with torch.cuda.device(attn.device):
+    with _native.on_device(attn.device):
         rc = _native.lib.datr_msda_prologue_backward_f32(
             d_loc.data_ptr(), d_attn.data_ptr(), attn.data_ptr(), ref.data_ptr(),
             d_both.numel() // 384, ref.shape[-1], d_both.data_ptr(),
@@ -541,7 +541,7 @@ class _StackLinear(torch.autograd.Function):
         Rb = wb.shape[0]
         w = torch.empty(Ra + Rb, C, device=wa.device, dtype=torch.float32)
         b = torch.empty(Ra + Rb, device=wa.device, dtype=torch.float32)
-        with torch.cuda.device(wa.device):
+        with _native.on_device(wa.device):
             rc = _native.lib.datr_stack_linear_forward_f32(
                 wa.data_ptr(), ba.data_ptr(), wb.data_ptr(), bb.data_ptr(), 0 if scale is None else scale.data_ptr(),
                 Ra, Rb, C, w.data_ptr(), b.data_ptr(), _native.current_stream_ptr(wa.device))
@@ -560,7 +560,7 @@ class _StackLinear(torch.autograd.Function):
             return dw[:Ra], db[:Ra], dw[Ra:], db[Ra:], None
         dwa = torch.empty(Ra, dw.shape[1], device=dw.device, dtype=torch.float32)
         dba = torch.empty(Ra, device=dw.device, dtype=torch.float32)
-        with torch.cuda.device(dw.device):
+        with _native.on_device(dw.device):
             rc = _native.lib.datr_stack_linear_backward_f32(dw.data_ptr(), db.data_ptr(), scale.data_ptr(), Ra,
                                                             dw.shape[1], dwa.data_ptr(), dba.data_ptr(),
                                                             _native.current_stream_ptr(dw.device))
@@ -743,7 +743,7 @@ class _ZeroRows(torch.autograd.Function):
 
 def _zero_rows_(x, mask):
     m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
-    with torch.cuda.device(x.device):
+    with _native.on_device(x.device):
         rc = _native.lib.datr_zero_rows_f32(x.data_ptr(), m.contiguous().data_ptr(), m.numel(), x.shape[-1],
                                             _native.current_stream_ptr(x.device))
     _native.check(rc, "zero_rows")

@@ -191,7 +191,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
         if used is not None:
             assert self._index is not None, "set_used_order() first"
             assert used.dtype == torch.int32 and used.is_cuda and used.is_contiguous()
-        with torch.cuda.device(t["device"]):
+        with _native.on_device(t["device"]):
             coef = 0
             if max_norm and max_norm > 0:
                 rc = _native.lib.datr_grad_norm_clip_coef_f32(t["tensors"].data_ptr(), t["pieces"].data_ptr(), t["npieces"],

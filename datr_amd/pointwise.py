@@ -71,7 +71,7 @@ class _Conv1x1(Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         if ctx.relu:                                                  # dz = dy * [y > 0], one pass
             dz = torch.empty_like(dy, memory_format=torch.channels_last)
-            with torch.cuda.device(dy.device):
+            with _native.on_device(dy.device):
                 rc = _native.lib.datr_affine_act_backward_f32(
                     dy.data_ptr(), y.data_ptr(), _ones(co, dy.device).data_ptr(), dy.numel(), co, 1, 1,
                     dz.data_ptr(), 0, _native.current_stream_ptr(dy.device))

@@ -90,7 +90,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
         lab = idxs.contiguous().to(torch.int64)
         keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
         count = torch.zeros(1, dtype=torch.int32, device=boxes.device)
-        with torch.cuda.device(boxes.device):
+        with _native.on_device(boxes.device):
             rc = _native.lib.datr_nms_f32(b.data_ptr(), s.data_ptr(), lab.data_ptr(), n, float(iou_threshold),
                                           keep.data_ptr(), count.data_ptr(),
                                           _native.current_stream_ptr(boxes.device))

@@ -57,14 +57,14 @@ class _Conv3x3S2(Function):
         wt = torch.empty(9 * C * co, device=x.device, dtype=torch.float32)
         wt_t = torch.empty(9 * C * co, device=x.device, dtype=torch.float32) if need_t else None
         sw = w.stride()
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_conv3x3s2_weights_f32(w.data_ptr(), co, C, sw[0], sw[1], sw[2], sw[3], wt.data_ptr(),
                                                         0 if wt_t is None else wt_t.data_ptr(),
                                                         _native.current_stream_ptr(x.device))
         _native.check(rc, "conv3x3s2_weights")
         y = torch.empty((N, co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         ws = _workspace(x.shape, co, x.device)
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_conv3x3s2_forward_nhwc_f32(
                 x.data_ptr(), wt.data_ptr(), 0 if scale is None else scale.data_ptr(),
                 0 if shift is None else shift.data_ptr(), 0.0 if relu else 1.0, N, H, W, C, co,
@@ -87,7 +87,7 @@ class _Conv3x3S2(Function):
             # dz = dy * [y > 0] * scale: the frozen-BN + ReLU backward pass (csrc/affine_act.hip)
             from .pointwise import _ones
             dz = torch.empty_like(dy, memory_format=torch.channels_last)
-            with torch.cuda.device(dy.device):
+            with _native.on_device(dy.device):
                 rc = _native.lib.datr_affine_act_backward_f32(
                     dy.data_ptr(), (y if ctx.relu else dy).data_ptr(),
                     (scale if scale is not None else _ones(co, dy.device)).data_ptr(), dy.numel(), co,
@@ -97,7 +97,7 @@ class _Conv3x3S2(Function):
             dz = dy
         dx = dw = db = None
         ws = _workspace(x.shape, co, x.device)
-        with torch.cuda.device(dy.device):
+        with _native.on_device(dy.device):
             if need[0]:
                 dx = torch.empty_like(x, memory_format=torch.channels_last)
                 rc = _native.lib.datr_conv3x3s2_dgrad_nhwc_f32(dz.data_ptr(), wt_t.data_ptr(), N, H, W, C, co,
@@ -125,7 +125,7 @@ class _EvenPixels(Function):
         N, C, H, W = x.shape
         y = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32,
                         memory_format=torch.channels_last)
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             rc = _native.lib.datr_even_pixels_nhwc_f32(x.data_ptr(), N, H, W, C, y.data_ptr(),
                                                        _native.current_stream_ptr(x.device))
         _native.check(rc, "even_pixels")
@@ -138,7 +138,7 @@ class _EvenPixels(Function):
         N, C, H, W = ctx.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-        with torch.cuda.device(dy.device):
+        with _native.on_device(dy.device):
             rc = _native.lib.datr_even_pixels_scatter_nhwc_f32(dy.data_ptr(), N, H, W, C, dx.data_ptr(),
                                                                _native.current_stream_ptr(dy.device))
         _native.check(rc, "even_pixels_scatter")
@@ -205,7 +205,7 @@ def stem_conv_bn_relu(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shi
     N, _, H, W = x.shape
     y = torch.empty((N, 64, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
+    with _native.on_device(x.device):
         rc = _native.lib.datr_stem_conv7x7_bn_relu_nhwc_f32(x.data_ptr(), wk.data_ptr(), scale.contiguous().data_ptr(),
                                                             shift.contiguous().data_ptr(), N, H, W, y.data_ptr(),
                                                             _native.current_stream_ptr(x.device))

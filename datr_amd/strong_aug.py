@@ -59,7 +59,7 @@ def pixel_ops_on_device(image: torch.Tensor, ops: Sequence[PixelOp]) -> torch.Te
         arr[k].shift = (int(factor * 255) & 0xFF) if code == HUE else 0
     sums = (torch.empty(PIXEL_OPS_MAX, dtype=torch.int64, device=image.device)
             if any(c == CONTRAST for c, _ in ops) else None)
-    with torch.cuda.device(image.device):
+    with _native.on_device(image.device):
         rc = _native.lib.datr_pixel_ops_u8(src.data_ptr(), dst.data_ptr(), src.shape[0] * src.shape[1],
                                            ctypes.cast(arr, ctypes.c_void_p), len(ops),
                                            0 if sums is None else sums.data_ptr(),
@@ -98,7 +98,7 @@ def gaussian_blur_on_device(image: torch.Tensor, sigma: float, passes: int = 3) 
     radius, ww, fw = box_weights(fr)
     src = image.contiguous()
     dst = torch.empty_like(src)
-    with torch.cuda.device(image.device):
+    with _native.on_device(image.device):
         rc = _native.lib.datr_box_blur_u8(src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], radius, ww, fw,
                                           passes, _native.current_stream_ptr(image.device))
     _native.check(rc, "box_blur_u8")

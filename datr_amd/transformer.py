@@ -177,7 +177,7 @@ def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
         nq, bs, nc = pos_tensor.shape
         pos = pos_tensor.contiguous()
         out = torch.empty(nq, bs, 128 * nc, device=pos.device, dtype=torch.float32)
-        with torch.cuda.device(pos.device):
+        with _native.on_device(pos.device):
             rc = _native.lib.datr_sine_embed_f32(pos.data_ptr(), dim_t.data_ptr(), nq * bs, nc,
                                                  out.data_ptr(), _native.current_stream_ptr(pos.device))
         _native.check(rc, "sine_embed")

@@ -37,7 +37,7 @@ def wino_filter(w: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
     if data_gradient:
         co, ci, s = ci, co, (s[1], s[0], s[2], s[3])
     u = torch.empty(16 * ci * co, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
+    with _native.on_device(w.device):
         rc = _native.lib.datr_wino_weights_f32(w.data_ptr(), co, ci, s[0], s[1], s[2], s[3],
                                                1 if data_gradient else 0, u.data_ptr(),
                                                _native.current_stream_ptr(w.device))
@@ -64,7 +64,7 @@ def wino_filter_pair(w: torch.Tensor):
     s = w.stride()
     u = torch.empty(16 * ci * co, device=w.device, dtype=torch.float32)
     uf = torch.empty(16 * ci * co, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
+    with _native.on_device(w.device):
         rc = _native.lib.datr_wino_weights_pair_f32(w.data_ptr(), co, ci, s[0], s[1], s[2], s[3], u.data_ptr(),
                                                     uf.data_ptr(), _native.current_stream_ptr(w.device))
     _native.check(rc, "wino_weights_pair")
@@ -90,7 +90,7 @@ def wino_conv3x3(xs, u: torch.Tensor, cout: int, shift=None, scale=None, slope: 
             assert g.shape == y.shape and g.is_contiguous(memory_format=torch.channels_last)
         levels[i] = _native.WinoLevel(x.data_ptr(), y.data_ptr(), 0 if g is None else g.data_ptr(),
                                       x.shape[2], x.shape[3])
-    with torch.cuda.device(xs[0].device):
+    with _native.on_device(xs[0].device):
         rc = _native.lib.datr_conv3x3_wino_nhwc_f32(
             ctypes.addressof(levels), len(xs), N, cin, cout, u.data_ptr(),
             0 if scale is None else scale.data_ptr(), 0 if shift is None else shift.data_ptr(),
@@ -122,7 +122,7 @@ def wino_wgrad(xs, dys, weight: torch.Tensor) -> torch.Tensor:
     partial = torch.empty(floats, device=weight.device, dtype=torch.float32)
     dw = torch.empty_like(weight)                                   # preserves the strides
     s = dw.stride()
-    with torch.cuda.device(weight.device):
+    with _native.on_device(weight.device):
         rc = _native.lib.datr_conv3x3_wino_wgrad_nhwc_f32(ctypes.addressof(levels), len(xs), N, ci, co,
                                                           partial.data_ptr(), dw.data_ptr(), s[0], s[1], s[2], s[3],
                                                           _native.current_stream_ptr(weight.device))
@@ -148,7 +148,7 @@ class _Conv3x3BnRelu(torch.autograd.Function):
         dy = _nhwc(dy)
         # dz = dy * [y > 0] * scale: the frozen-BN + ReLU backward pass (csrc/affine_act.hip)
         dz = torch.empty_like(dy, memory_format=torch.channels_last)
-        with torch.cuda.device(dy.device):
+        with _native.on_device(dy.device):
             rc = _native.lib.datr_affine_act_backward_f32(
                 dy.data_ptr(), y.data_ptr(), scale.data_ptr(), dy.numel(), dy.shape[1], 1, 1, dz.data_ptr(), 0,
                 _native.current_stream_ptr(dy.device))
