@@ -113,6 +113,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
                     raise TypeError("FusedClipAdamW: float32 device parameters only")
                 if gr.stride() != strides and not _same_layout(gr, p):   # e.g. an NCHW gradient of a channels_last weight
                     gr = p.grad = torch.empty_like(p).copy_(gr)
+                    self._relaid = True
                 dev = p.device
                 # -1 = no used flag for this tensor (the kernel then always updates it); once an order is set a
                 # parameter missing from it would silently follow another parameter's flag: refuse
@@ -149,10 +150,12 @@ class FusedClipAdamW(torch.optim.Optimizer):
         sig = self._signature()
         if self._tables is not None and self._tables.get("sig") == sig:
             return self._tables
+        self._relaid = False
         rows, pieces, dev, params = self._build()
         if not rows:
             return None
-        sig = self._signature()                       # (_build may have re-laid a gradient out)
+        if self._relaid:
+            sig = self._signature()                   # (_build re-laid a gradient out: another address)
         key = tuple(rows)
         t = self._tables
         if t is None or t["key"] != key:

@@ -28,4 +28,6 @@ run_steps(state, [b] * 10)
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 35)
+top = int(sys.argv[1]) if len(sys.argv) > 1 else 35
+st.sort_stats("tottime").print_stats(top)
+st.sort_stats("cumulative").print_stats(r"datr_amd|torch/autograd/function|engine", top)
