@@ -364,8 +364,22 @@ class Backbone(nn.Module):
         self.body = _StageOutputs(trunk, return_layers)
         self.num_channels = [256, 512, 1024, 2048][4 - n:]
 
+    def _nhwc_trunk(self) -> bool:
+        """True when the trunk was moved to torch.channels_last (its first convolution's weight says so)."""
+        for mod in self.body.modules():
+            if isinstance(mod, nn.Conv2d):
+                w = mod.weight
+                return w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous()
+        return False
+
     def forward(self, tensor_list: NestedTensor):
-        feats = self.body(tensor_list.tensors)
+        x = tensor_list.tensors
+        if (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
+                and not x.is_contiguous(memory_format=torch.channels_last) and self._nhwc_trunk()):
+            # an NCHW batch (the reference's collate function builds one, util/misc.py:387-409) into an NHWC trunk:
+            # one pass over the images here instead of the whole backbone on the library's NCHW path
+            x = x.contiguous(memory_format=torch.channels_last)
+        feats = self.body(x)
         out: Dict[str, NestedTensor] = {}
         m = tensor_list.mask
         assert m is not None

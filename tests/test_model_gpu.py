@@ -363,3 +363,26 @@ def test_eval_forward_and_postprocess_on_device():
     assert torch.equal(torch.stack([r["labels"] for r in res_ref]).cpu(), t(g["labels"]))
     torch.testing.assert_close(torch.stack([r["scores"] for r in res_ref]).cpu(), t(g["scores"]), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(torch.stack([r["boxes"] for r in res_ref]).cpu(), t(g["boxes"]), rtol=1e-5, atol=1e-4)
+
+
+def test_nchw_batch_into_an_nhwc_backbone_takes_the_nhwc_kernels():
+    """A batch in the reference's layout (contiguous NCHW, what util/misc.py:387-409 collates) handed to a backbone
+    that was moved to channels_last: the features are the NHWC run's, bit for bit, and channels_last themselves -- the
+    trunk converts the images once instead of running on the library's NCHW path."""
+    import torch
+    from datr_amd.nested import NestedTensor
+    from helpers import build_model
+    dev = torch.device("cuda:0")
+    args, model, criterion, _ = build_model("cuda:0")
+    model.backbone.to(memory_format=torch.channels_last)
+    model.eval()
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 3, 256, 320, generator=g).to(dev)
+    mask = torch.zeros(2, 256, 320, dtype=torch.bool, device=dev)
+    with torch.no_grad():
+        a, _ = model.backbone(NestedTensor(img.contiguous(), mask, False))
+        b, _ = model.backbone(NestedTensor(img.contiguous(memory_format=torch.channels_last), mask, False))
+    assert img.contiguous().is_contiguous() and len(a) == len(b) >= 3
+    for fa, fb in zip(a, b):
+        assert fa.tensors.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(fa.tensors, fb.tensors)
