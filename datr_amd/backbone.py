@@ -9,7 +9,8 @@ The ResNet-50 arithmetic itself is NOT in the reference tree: it comes from torc
 public v1.5 architecture (stride on the 3x3 conv of each bottleneck) with torchvision's
 parameter names so that DATR / DINO checkpoints load unchanged
 (`backbone.0.body.layerK.J.{conv,bn}N.*`).  Parity for it is unpinned by any
-reference test; tests/test_backbone.py pins shapes, names and the frozen-BN algebra.
+reference test; tests/test_backbone_cpu.py / test_backbone_gpu.py pin names, shapes, the trainable split and
+the arithmetic against oracle/resnet_ref.py (a plain-nn restatement that shares no code with this file).
 """
 from __future__ import annotations
 

@@ -46,6 +46,18 @@ def c2f_args(**overrides) -> argparse.Namespace:
     return argparse.Namespace(**cfg)
 
 
+def sim10k_args(**overrides) -> argparse.Namespace:
+    """Sim10k -> Cityscapes (/root/reference/config/DA/Sim10k2Cityscapes/DINO_4scale_sim2cityscapes.py): the C2F
+    values with `num_classes = dn_labelbook_size = 2` (:3,109 -- one foreground class, `car`)."""
+    return c2f_args(**{**dict(num_classes=2, dn_labelbook_size=2, dataset_file="sim2city"), **overrides})
+
+
+def bdd_args(**overrides) -> argparse.Namespace:
+    """Cityscapes -> BDD100K-daytime (/root/reference/config/DA/Cityscapes2BDD100k/DINO_4scale_city2BDD100k.py):
+    identical to C2F on the hot path (the files differ only in the data-transform base they name)."""
+    return c2f_args(**{**dict(dataset_file="city2bdd"), **overrides})
+
+
 def get_param_dict(args, model_without_ddp):
     """'default' grouping (/root/reference/util/get_param_dicts.py:23-31): everything whose
     name contains "backbone" trains at lr_backbone, the rest at lr."""

@@ -12,8 +12,9 @@ Stand-ins:
   MultiScaleDeformableAttention  -> forward = the reference's own
         ms_deform_attn_core_pytorch, backward = autograd through it
   torchvision                    -> __version__, _is_tracing, ops.boxes.{box_area,
-        nms, batched_nms}, ops.misc.interpolate, models.resnet50 (datr_amd's
-        ResNet-50 v1.5), models._utils.IntermediateLayerGetter, transforms stubs
+        nms, batched_nms}, ops.misc.interpolate, models.resnet50 (oracle/resnet_ref.py:
+        plain nn.Conv2d / norm / ReLU ResNet-50 v1.5 -- NOT the product's class),
+        models._utils.IntermediateLayerGetter, transforms stubs
   timm / cv2 / pycocotools / panopticapi / addict / yapf / termcolor -> empty shells
 """
 from __future__ import annotations
@@ -166,12 +167,11 @@ def install(neutralise_cuda: bool = True):
     ops.boxes, ops.misc, ops.nms, ops.batched_nms = boxes, misc, _nms, _batched_nms
     tv.ops = ops
 
-    def _resnet50(replace_stride_with_dilation=None, pretrained=False, norm_layer=None, **kw):
-        from datr_amd.backbone import ResNet50Body
-        assert not replace_stride_with_dilation or not any(replace_stride_with_dilation)
-        return ResNet50Body(norm_layer=norm_layer)
+    # torchvision's ResNet-50: oracle/resnet_ref.py, a plain-nn restatement of the public architecture
+    # that imports nothing from the product (the product is what the fixtures are compared WITH)
+    from . import resnet_ref
 
-    models = _module("torchvision.models", resnet50=_resnet50)
+    models = _module("torchvision.models", resnet50=resnet_ref.resnet50)
     models_utils = _module("torchvision.models._utils",
                            IntermediateLayerGetter=_IntermediateLayerGetter)
     models._utils = models_utils

@@ -9,6 +9,8 @@ its weights with tests/golden/synth.py's deterministic tensors, and records
                    dict, the weighted total, the Hungarian indices of all 7 matcher calls,
                    per-parameter gradient norms, the running prototypes after the step, and
                    the four random draws of prepare_for_cdn (dn_components.py:64-66,84-85)
+  model_step_sim10k.npz   the same step with the Sim10k -> Cityscapes config (num_classes = 2,
+                   /root/reference/config/DA/Sim10k2Cityscapes/DINO_4scale_sim2cityscapes.py)
   model_eval.npz   eval-mode forward of the same images + PostProcess(num_select=100)
   model_units.npz  direct calls of the small functions on the path (position embedding,
                    sine query embedding, encoder proposals, focal loss, matcher cost, ...)
@@ -75,12 +77,19 @@ def flatten_indices(indices_list):
                      for call in indices_list])
 
 
-def main():
-    args = ref_shims.load_config()
+C2F_CONFIG = "config/DA/Cityscapes2FoggyCityscapes/DINO_4scale_C2F.py"
+SIM10K_CONFIG = "config/DA/Sim10k2Cityscapes/DINO_4scale_sim2cityscapes.py"     # num_classes = dn_labelbook_size = 2
+
+
+def training_step(config, num_classes, out_name):
+    """One training forward + criterion + backward of the reference model built from `config`;
+    writes tests/golden/<out_name> and returns (model, imgs) for the eval leg."""
+    args = ref_shims.load_config(config)
+    assert args.num_classes == num_classes and args.dn_labelbook_size == num_classes
     torch.manual_seed(0)
     model, criterion, post = build_dino(args)
     synth.synth_init_(model)
-    imgs, targets = synth.synth_batch()
+    imgs, targets = synth.synth_batch(num_classes=num_classes)
 
     # ---------------- training step ---------------------------------------------------------
     model.train()
@@ -163,8 +172,16 @@ def main():
         rec_["grad::" + k] = to_np(g if g.numel() < 5000 else g.flatten()[:5000])
     rec_["state_keys"] = np.array(list(sd.keys()))
     rec_["state_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
-    np.savez_compressed(os.path.join(OUT, "model_step.npz"), **rec_)
-    print("wrote model_step.npz; total loss", float(total), "keys", len(loss_dict))
+    np.savez_compressed(os.path.join(OUT, out_name), **rec_)
+    print("wrote", out_name, "; total loss", float(total), "keys", len(loss_dict))
+    return model, imgs
+
+
+def main():
+    model, imgs = training_step(C2F_CONFIG, 9, "model_step.npz")
+    # the Sim10k -> Cityscapes task (README.md:115): one foreground class, so the class heads are [2, 256],
+    # label_enc [3, 256], prototypes [2, 256] -- the shapes the per-class kernels see with C = 2
+    training_step(SIM10K_CONFIG, 2, "model_step_sim10k.npz")
 
     # ---------------- eval forward + post-process ---------------------------------------------
     model.eval()

@@ -68,13 +68,13 @@ def synth_init_(model: torch.nn.Module) -> None:
             v.copy_(_gen(canon, v.shape, _kind(canon, v)).to(v.dtype))
 
 
-def synth_batch(seed=1, sizes=((256, 320), (240, 300)), num_gt=3):
+def synth_batch(seed=1, sizes=((256, 320), (240, 300)), num_gt=3, num_classes=9):
     """One source + one target image (different sizes -> non-trivial padding masks) and the
-    source image's ground truth."""
+    source image's ground truth (labels 1 .. num_classes - 1: the configs count the background slot)."""
     g = torch.Generator().manual_seed(seed)
     imgs = [torch.randn(3, h, w, generator=g) for h, w in sizes]
     cxcy = torch.rand(num_gt, 2, generator=g) * 0.5 + 0.25
     wh = torch.rand(num_gt, 2, generator=g) * 0.2 + 0.05
-    labels = torch.randint(1, 9, (num_gt,), generator=g)
+    labels = torch.randint(1, num_classes, (num_gt,), generator=g)
     targets = [{"boxes": torch.cat([cxcy, wh], 1), "labels": labels}]
     return imgs, targets

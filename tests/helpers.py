@@ -57,11 +57,11 @@ def patch_msda_with_oracle(monkeypatch, kind="c"):
     monkeypatch.setattr(criterion, "focal_loss_sums", focal_oracle.focal_sums_torch)
 
 
-def build_model(device="cpu"):
+def build_model(device="cpu", task="c2f"):
     import synth
-    from datr_amd.config import c2f_args
+    from datr_amd import config
     from datr_amd.detector import build_dino
-    args = c2f_args(device=device)
+    args = {"c2f": config.c2f_args, "sim10k": config.sim10k_args}[task](device=device)
     torch.manual_seed(0)
     model, criterion, post = build_dino(args)
     synth.synth_init_(model)
@@ -96,12 +96,12 @@ def force_reference_selection(model, golden, device):
     model.transformer.select_queries = forced
 
 
-def run_training_step(model, criterion, device, golden, channels_last=False):
+def run_training_step(model, criterion, device, golden, channels_last=False, num_classes=9):
     """One training forward + criterion + backward with the golden's CDN noise injected.
     channels_last: the images (and whatever the caller did to the model) in NHWC -- bench.py's layout."""
     import synth
     from datr_amd.nested import nested_tensor_from_tensor_list
-    imgs, targets = synth.synth_batch()
+    imgs, targets = synth.synth_batch(num_classes=num_classes)
     samples = nested_tensor_from_tensor_list([i.to(device) for i in imgs])
     if channels_last:
         samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)

@@ -111,6 +111,22 @@ def test_full_training_step_matches_reference(monkeypatch):
     check_gradients(model, g, rtol=1e-4)
 
 
+def test_sim10k_training_step_matches_reference(monkeypatch):
+    """The Sim10k -> Cityscapes task (num_classes = 2: class heads [2, 256], label_enc [3, 256], prototypes
+    [2, 256]) against the reference's own step with that config (model_step_sim10k.npz)."""
+    patch_msda_with_oracle(monkeypatch, kind="grid_sample")
+    g = load_npz("model_step_sim10k.npz")
+    args, model, criterion, _ = build_model(task="sim10k")
+    assert args.num_classes == 2 and model.class_embed[0].weight.shape == (2, 256)
+    assert [str(k) for k in g["state_keys"]] == list(model.state_dict().keys())
+    assert [str(s) for s in g["state_shapes"]] == [",".join(map(str, v.shape)) for v in model.state_dict().values()]
+    model.merge_encoder_passes = False
+    out, loss_dict, indices_list, total = run_training_step(model, criterion, "cpu", g, num_classes=2)
+    assert len(loss_dict) == 82 and out["pred_logits"].shape[-1] == 2
+    check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-5, loss_rtol=1e-5)
+    check_gradients(model, g, rtol=1e-4)
+
+
 def test_merged_encoder_pass_matches_reference(monkeypatch):
     """Default mode: ONE encoder call for the source and target halves.  Values agree with the
     reference to fp32 rounding; with the top-900 selection pinned (the forward's one

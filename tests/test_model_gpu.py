@@ -76,6 +76,28 @@ def test_step_with_reference_selection_matches_elementwise():
     assert d < 2e-4, float(d)
 
 
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_sim10k_step_with_reference_selection_matches_elementwise(nhwc):
+    """The reference's second published task, Sim10k -> Cityscapes (README.md:115; config
+    config/DA/Sim10k2Cityscapes/DINO_4scale_sim2cityscapes.py: num_classes = dn_labelbook_size = 2), on the
+    HIP path against the reference's own step with that config (tests/golden/model_step_sim10k.npz): the
+    per-class kernels (class max of the two-stage scores, focal loss, matching cost, prototypes, label
+    flips of the denoising queries) run with C = 2 here.  Same bars as the C2F step: logits / boxes within
+    1e-3, Hungarian indices of all 7 matcher calls bit-exact, 82 losses, gradients."""
+    dev = torch.device("cuda:0")
+    g = load_npz("model_step_sim10k.npz")
+    args, model, criterion, _ = build_model("cuda:0", task="sim10k")
+    assert args.num_classes == 2 and model.class_embed[0].weight.shape == (2, 256)
+    if nhwc:
+        model.backbone.to(memory_format=torch.channels_last)
+    force_reference_selection(model, g, dev)
+    out, loss_dict, indices_list, total = run_training_step(model, criterion, dev, g, channels_last=nhwc,
+                                                            num_classes=2)
+    assert out["pred_logits"].shape[-1] == 2 and len(loss_dict) == 82
+    check_training_step(model, out, loss_dict, indices_list, total, g, logit_tol=1e-3, loss_rtol=2e-3)
+    check_gradients(model, g, rtol=3e-2 if nhwc else 2e-2, outlier_fraction=0.05 if nhwc else 0.0)
+
+
 def test_nhwc_step_with_reference_selection_matches_elementwise(monkeypatch):
     """The same element-wise comparison in the layout bench.py trains in: backbone and images in
     torch.channels_last, which routes conv2 + frozen BN + ReLU of the narrow bottlenecks through the

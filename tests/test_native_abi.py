@@ -83,6 +83,22 @@ def test_product_never_imports_oracle():
                 assert "libdatr_oracle" not in src, f
 
 
+def test_oracle_and_fixtures_never_import_the_product():
+    """The mirror of the rule above: the oracle (oracle/) and the fixture generators (tests/golden/) must not
+    import datr_amd -- a fixture produced with product code inside would compare the product with itself.
+    (The third-party stand-ins the reference needs, e.g. torchvision's ResNet-50, live in oracle/ as plain
+    torch.nn restatements: oracle/resnet_ref.py.)"""
+    pat = re.compile(r"^\s*(from\s+datr_amd\b|import\s+datr_amd\b)|__import__\(\s*[\"']datr_amd|"
+                     r"import_module\(\s*[\"']datr_amd", flags=re.M)
+    for sub in ("oracle", os.path.join("tests", "golden")):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".c", ".h")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not pat.search(src), os.path.join(dirpath, f)
+                    assert "libdatr_hip" not in src, f
+
+
 def test_module_state_dict_names_and_init():
     from datr_amd.msda import MSDeformAttn
     m = MSDeformAttn(256, 4, 8, 4)
