@@ -265,6 +265,48 @@ def msda_trained_like_roofline(device, shape, sigma=2.5):
                          "frac": round(algo_b / bus / 1e3 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": algo_b}}
 
 
+def msda_n2_launch_us(device):
+    """The encoder forward launch at the CPU leg's shape -- N = 2, S = Lq = 22 223, M = 8, D = 32, L = P = 4 --
+    MEASURED as its own launches (round 5 quoted the merged N = 4 launch / 2): (a) on the CPU leg's own inputs
+    (`oracle.msda_oracle.random_inputs(seed=3)`: loc ~ U[0,1), the reference op test's recipe, moved to the
+    device), (b) with the sampling locations a freshly initialised encoder produces (pixel-centre reference
+    points + the ring offsets of ms_deform_attn.py:59-68: head m looks along angle 2 pi m / 8, point p at
+    p + 1 pixels), the regime of the timed step.  HIP events, mean of 10 launches after 3 warm-up launches."""
+    import math
+    from datr_amd import msda
+    from oracle import msda_oracle as O      # input generator of the CPU leg only; nothing of it is timed here
+    shapes_l = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes_l)
+    value, sh, lsi, loc, attn = O.random_inputs(2, S, 8, 32, shapes_l, 4, seed=3)
+    value, loc, attn, sh, lsi = (x.to(device) for x in (value, loc, attn, sh, lsi))
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        b.record()
+        b.synchronize()
+        return round(a.elapsed_time(b) * 1e3 / 10, 2)
+    out = {"same_inputs_as_cpu_leg_us": timed(lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc, attn, 64))}
+    refs = []
+    for h, w in shapes_l:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0).view(1, S, 1, 1, 1, 2)
+    th = torch.arange(8, dtype=torch.float32) * (2.0 * math.pi / 8)
+    ring = torch.stack([th.cos(), th.sin()], -1)
+    ring = (ring / ring.abs().max(-1, keepdim=True)[0]).view(1, 1, 8, 1, 1, 2) * \
+        torch.arange(1, 5, dtype=torch.float32).view(1, 1, 1, 1, 4, 1)
+    wh = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+    loc_r = (ref + ring / wh).expand(2, S, 8, 4, 4, 2).contiguous().to(device)
+    env = msda.measure_envelope(loc_r, sh)
+    out["ring_offsets_us"] = timed(lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc_r, attn, 64, envelope=env))
+    return out
+
+
 def trained_like_step_ms(state, pool, steps, sigma=2.5):
     """Step time with encoder offsets of a trained-like spread: every encoder layer's `sampling_offsets`
     gets weights ~ N(0, (sigma / 26)^2) and a zero bias, so that its offsets are ~ N(0, sigma px) and
@@ -576,6 +618,76 @@ def _gemm_backend(args):
         f" [{gemm.BACKEND_REASON}]"
 
 
+def pin_to_local_cores(local_rank: int, local_world: int):
+    """One process per GPU on one host: give every rank its own slice of the host cores, on the NUMA node
+    its GPU hangs off when sysfs says which (the reference leaves placement to the launcher, main.py:138,156
+    run under torch.distributed.launch; eight un-pinned ranks migrate and share caches).  Returns a
+    description for the bench line; None when affinity cannot be set here."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    if local_world <= 1 or len(avail) < local_world:
+        return {"cpus": len(avail), "pinned": False}
+    node, node_cpus = None, None
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node >= 0:
+            cpus = []
+            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus += list(range(int(a), int(b or a) + 1))
+            node_cpus = [c for c in cpus if c in set(avail)]
+    except (OSError, ValueError, AttributeError, AssertionError, RuntimeError):
+        node, node_cpus = None, None
+    per = max(1, len(avail) // local_world)
+    mine = avail[local_rank * per:(local_rank + 1) * per]
+    how = "contiguous slice of the allowed cores"
+    if node_cpus and len(node_cpus) >= per:
+        # ranks whose GPUs share the node split it: position among them by local rank order
+        sharers = max(1, local_world * len(node_cpus) // len(avail))
+        k = local_rank % sharers
+        per_n = max(1, len(node_cpus) // sharers)
+        mine = node_cpus[k * per_n:(k + 1) * per_n]
+        how = f"NUMA node {node} of the rank's GPU"
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return {"cpus": len(avail), "pinned": False}
+    torch.set_num_threads(max(1, min(len(mine), 8)))
+    return {"cpus": len(mine), "first_cpu": mine[0], "pinned": True, "how": how, "numa_node": node}
+
+
+def rank_diagnostics(state, step_diag, elapsed_local, steps, world, device):
+    """What `bench.py --gpus N` says about WHERE a multi-rank step spends its time, per rank (gathered on
+    rank 0): the rank's own time per step, the host's enqueue time per step (the loop is host-bound when this
+    approaches the step time), how long the host then waits for the losses, and the span on the compute
+    stream between "last bucket launched" and "every all-reduce done" in reducer.finish() -- the part of the
+    gradient exchange NOT overlapped with backward."""
+    mine = {"ms_per_step": round(elapsed_local / steps * 1e3, 2)}
+    if step_diag:
+        d = step_diag[-steps:]
+        mine["host_enqueue_ms"] = round(sum(x["host_enqueue_ms"] for x in d) / len(d), 2)
+        mine["loss_wait_ms"] = round(sum(x["loss_wait_ms"] for x in d) / len(d), 2)
+    red = state.reducer
+    if red is not None and red.diag:
+        d = red.diag[-steps:]
+        spans = [a.elapsed_time(b) for a, b in (x["events"] for x in d) if a is not None and b is not None]
+        if spans:
+            mine["exposed_allreduce_ms"] = round(sum(spans) / len(spans), 3)
+        mine["finish_host_ms"] = round(sum(x["host_ms"] for x in d) / len(d), 3)
+        mine["buckets_launched_in_finish"] = round(sum(x["buckets_launched_in_finish"] for x in d) / len(d), 2)
+        mine["buckets"] = len(red.buckets)
+        mine["allreduce_bytes"] = red.total_bytes
+    if world > 1:
+        out = [None] * world
+        dist.all_gather_object(out, mine)
+        return out
+    return [mine]
+
+
 def relaunch_with_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under
     torch.distributed.run on this node (the command line the driver uses) and pass its output
@@ -644,6 +756,8 @@ def main():
             "the multi-GPU bench runs over RCCL (torch.distributed backend 'nccl'); --allow-gloo is for tests"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    affinity = pin_to_local_cores(int(os.environ.get("LOCAL_RANK", "0")),
+                                  int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
 
     state = build_training(device=device, rank=rank, channels_last=args.channels_last,
                            tuned_gemm=args.tuned_gemm,
@@ -685,11 +799,22 @@ def main():
 
     fence()
     timer.enabled = True
+    # per-step host / reducer diagnostics: two clock reads per step and, with a reducer, one event pair
+    from datr_amd import engine as engine_mod
+    step_diag = engine_mod.STEP_DIAG = []
+    if state.reducer is not None:
+        state.reducer.diag = []
     t0 = time.perf_counter()
     run_steps(state, marked(batches(args.steps, args.warmup)))
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    engine_mod.STEP_DIAG = None
+    ranks = rank_diagnostics(state, step_diag, elapsed_local, args.steps, world, device)
+    if state.reducer is not None:
+        state.reducer.diag = None
     per_step_raw = [a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:])]
     per_step = sorted(per_step_raw)
 
@@ -749,7 +874,18 @@ def main():
             "ms_per_step_each": [round(v, 1) for v in per_step_raw] if os.environ.get("DATR_BENCH_PER_STEP") else None,
             "padded_batch_ms_per_step": padded_ms,
             "roofline": roof,
+            # 7.17 TFLOP of convolution / linear work per step at B = 2 (fwd 1253.5 + bwd 2331.0
+            # GFLOP per image pair, counted on the reference) against the dense fp32-MFMA peak: the figure that
+            # describes the ~93 % of the step's GPU time that is matrix work
+            "step_roofline": None if source_only else {
+                "bound": "mfma", "flops": 3584.5e9 * args.batch, "unit": "TFLOP/s", "peak": MFMA_FP32_PEAK_TFLOPS,
+                "achieved": round(3584.5e9 * args.batch / (elapsed / args.steps) / 1e12, 2),
+                "frac": round(3584.5e9 * args.batch / (elapsed / args.steps) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
+                "note": "valid at 1333x800 only (the FLOP count is for that size); per GPU"} if
+            (args.height, args.width) == (800, 1333) else None,
+            "ranks": ranks,
         }
+        line["config"]["cpu_affinity"] = affinity
         line["roofline_backward"] = timer.backward_result()
         if timer.shape is not None:
             line["roofline_rand_locations"] = msda_rand_roofline(device, timer.shape)
@@ -782,9 +918,14 @@ def main():
             hip_c1 = config1_device_step(state)
             if dist.is_initialized():       # one-rank RCCL mode: the CPU leg must not see a NCCL group
                 dist.destroy_process_group()
-            # GPU time of the op at the CPU leg's shape (N=2): the merged N=4 launch / 2
-            gpu_us = roof["mean_us"] * 2 / timer.shape[0] if roof else None
-            line["cpu_baseline"] = cpu_baseline(gpu_us)
+            # GPU time of the op at the CPU leg's shape (N = 2): measured launches of that shape
+            n2 = msda_n2_launch_us(device)
+            line["cpu_baseline"] = cpu_baseline(n2["ring_offsets_us"])
+            line["cpu_baseline"]["msda_op"]["hip_fwd_ms_same_inputs"] = round(n2["same_inputs_as_cpu_leg_us"] / 1e3, 4)
+            line["cpu_baseline"]["msda_op"]["hip_fwd_source"] = (
+                "measured N = 2 launches (HIP events, mean of 10): `hip_fwd_ms_same_shape` with the ring-initialised "
+                "sampling offsets of the timed step, `hip_fwd_ms_same_inputs` on the CPU leg's own tensors "
+                "(loc ~ U[0,1): the row kernel)")
             line["cpu_baseline"]["config1_source_only"]["hip_same_shape"] = hip_c1
         # RCCL writes its version banner through C stdio, which sits in a buffer when stdout is a pipe
         # and would come out AFTER this line at exit: push it out first, the JSON line stays the last one

@@ -39,6 +39,7 @@ identity, as `nn.Module.parameters()` already does.
 """
 from __future__ import annotations
 
+import time
 import weakref
 from typing import List, Optional
 
@@ -160,6 +161,10 @@ class GradAllReducer:
         self._used_events = [None] * len(self._used_stage)      # the device copy that last read each staging buffer
         self._used = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._used_work = None
+        # diagnostics (bench.py --gpus N): a list here receives one record per finish() -- HIP events around the
+        # wait for the outstanding all-reduces on the compute stream (their span = communication NOT hidden
+        # behind backward), the host time of finish() and how many buckets were only launched there
+        self.diag = None
 
     # -- bucket layout --------------------------------------------------------------------------
     def _build(self, order: List[int]):
@@ -313,9 +318,15 @@ class GradAllReducer:
         missing gradients will never come: unused parameters this step), waits for every gather /
         all-reduce and averages.  Afterwards every bucketed parameter's .grad is its slice of
         the flat buffer."""
+        t_host = time.perf_counter() if self.diag is not None else 0.0
+        late = len(self.buckets) - self._next
         for b in self.buckets[self._next:]:
             self._launch(b)
         self._next = len(self.buckets)
+        ev0 = None
+        if self.diag is not None and self._used.is_cuda:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         # every bucket is gathered: this rank's used flags are complete
         self._used.copy_(self._used_stage[self._used_turn], non_blocking=True)
         if self._used.is_cuda:
@@ -334,6 +345,13 @@ class GradAllReducer:
         if self._used_work is not None:
             self._used_work.wait()
             self._used_work = None
+        if self.diag is not None:
+            ev1 = None
+            if ev0 is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+            self.diag.append({"events": (ev0, ev1), "host_ms": (time.perf_counter() - t_host) * 1e3,
+                              "buckets_launched_in_finish": late})
         if self._arrival is not None:
             self._rebuild_from_first_step()
             for b in self.buckets:      # re-home this step's (already reduced) gradients; the used flags are on

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import sys
+import time
 from collections import defaultdict
 from typing import Iterable
 
@@ -67,6 +68,12 @@ def _check_finite(loss_value, loss_dict_reduced):
 
 
 _GC_FROZEN = [False, 0]         # done?, training steps seen by this process
+
+# Diagnostics (bench.py --gpus N): a list here receives one dict per training step with the host's side of
+# it -- `host_enqueue_ms`: batch move + forward + criterion + backward + reduce + clip + step ENQUEUED (the
+# host is free again), `loss_wait_ms`: what the host then waits for the step's loss values (the one blocking
+# point of the loop).  None = off: two clock reads per step are not taken.
+STEP_DIAG = None
 
 
 def _settle_garbage_collector(steps_done: int = 0) -> None:
@@ -142,6 +149,8 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     last = {}
     steps = 0
     for samples, targets, _, _ in data_loader:
+        diag = STEP_DIAG
+        t_begin = time.perf_counter() if diag is not None else 0.0
         samples = samples.to(device)
         targets = [{k: v.to(device) for k, v in t.items()} for t in targets]
         if hasattr(criterion, "prefetch_num_boxes"):
@@ -155,7 +164,11 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         loss_dict_reduced = {k: v.detach() for k, v in reduce_dict(loss_dict).items()}
         fetch = _LossFetch(loss_dict_reduced, weight_dict)
         _backward_and_step(model, optimizer, losses, max_norm, scaler, amp, reducer)
+        t_enqueued = time.perf_counter() if diag is not None else 0.0
         scaled, unscaled = fetch.result()
+        if diag is not None:
+            diag.append({"host_enqueue_ms": (t_enqueued - t_begin) * 1e3,
+                         "loss_wait_ms": (time.perf_counter() - t_enqueued) * 1e3})
         loss_value = sum(scaled.values())
         _check_finite(loss_value, loss_dict_reduced)
         if getattr(args, "onecyclelr", False):

@@ -45,10 +45,32 @@ def set_backend(name: str, reason: str, tuned_rows=None) -> None:
     TUNED_ROWS = None if tuned_rows is None else frozenset(tuned_rows)
 
 
+def within_kernel_limits(shapes, row_strides) -> bool:
+    """The size limits of `datr_gemm_f32` (csrc/gemm_f32.hip: 32-bit buffer offsets) over the operands of one
+    product, whatever its form -- conservative: an operand must stay below 2 GiB, the output (at most
+    rows x the widest dimension in sight, which also bounds rows x ldc / ldr / ldg for row-major outputs of that
+    width) below 2^29 elements, and a weight's output-feature count must be a multiple of 4.  `shapes` /
+    `row_strides`: per operand (rows, cols) and the row stride in elements; the first operand carries the tokens."""
+    rows = shapes[0][0]
+    widest = max(max(r if r != rows else 0, c) for r, c in shapes)
+    if rows * max(widest, 1) >= 1 << 29:
+        return False
+    for (r, c), ld in zip(shapes, row_strides):
+        if ((r - 1) * ld + c) * 4 >= 0x80000000 - 16:
+            return False
+        if r * ld >= 1 << 29:
+            return False
+        if r != rows and r % 4:          # NT: output features; NN: K (already a multiple of 32 by the caller's rule)
+            return False
+    return True
+
+
 def own_big(*mats) -> bool:
     """True when the large product over these row-major operands goes to the own family: backend "own" (or a row
-    count the library's selections do not cover, see TUNED_ROWS), at least BIG_ROWS rows in the first operand, every operand 2-d float32 on the device with a unit last stride,
-    16-byte aligned rows and a feature count that is a multiple of 32 (what every kernel form accepts)."""
+    count the library's selections do not cover, see TUNED_ROWS), at least BIG_ROWS rows in the first operand, every
+    operand 2-d float32 on the device with a unit last stride, 16-byte aligned rows and a feature count that is a
+    multiple of 32 (what every kernel form accepts), and the product inside the kernels' size limits
+    (`within_kernel_limits`: beyond them -- e.g. an FFN hidden of >= 262 144 rows -- the library runs it, as before)."""
     rows = mats[0].shape[0]
     if rows < BIG_ROWS:
         return False
@@ -58,7 +80,7 @@ def own_big(*mats) -> bool:
         if not (t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and t.shape[1] % 32 == 0
                 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
             return False
-    return True
+    return within_kernel_limits([tuple(t.shape) for t in mats], [t.stride(0) for t in mats])
 
 
 def _workspace(device, stream: int, floats: int):

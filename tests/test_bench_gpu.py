@@ -39,6 +39,17 @@ def test_bench_two_gloo_ranks_share_the_gpu_and_rank0_prints_the_line_last():
     # whole-job aggregate: images of BOTH ranks over the max-over-ranks time
     assert line["value"] > 0 and line["ms_per_step"] > 0
     assert abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 0.02
+    # the multi-rank diagnosis (one record per rank, gathered on rank 0): the rank's own step time, the host's
+    # enqueue time and loss wait per step, the gradient exchange left exposed after backward, the core pinning
+    ranks = line["ranks"]
+    assert len(ranks) == 2
+    for r in ranks:
+        assert r["ms_per_step"] > 0 and r["ms_per_step"] <= line["ms_per_step"] * 1.05
+        assert r["host_enqueue_ms"] > 0 and r["loss_wait_ms"] >= 0
+        assert r["finish_host_ms"] >= 0 and r["buckets"] >= 1 and r["allreduce_bytes"] > 190e6
+        assert "exposed_allreduce_ms" in r and r["exposed_allreduce_ms"] >= 0
+    aff = cfg["cpu_affinity"]
+    assert aff is not None and ("pinned" in aff)
 
 
 @pytest.mark.gpu

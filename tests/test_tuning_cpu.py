@@ -40,3 +40,23 @@ def test_own_big_routes_untuned_row_counts(monkeypatch):
     assert not gemm.own_big(Mat(87040, 256), w)
     monkeypatch.setattr(gemm, "BACKEND", "own")
     assert gemm.own_big(Mat(88892, 256), w) and gemm.own_big(Mat(87040, 256), w)
+
+
+def test_own_family_size_limits_route_oversized_products_to_the_library():
+    """csrc/gemm_f32.hip returns DATR_EUNSUPPORTED beyond its 32-bit offsets (an operand of 2 GiB, or
+    rows x N / rows x ld >= 2^29); `gemm.own_big` must decline those products instead of letting every
+    call site raise -- the library ran them before the own family became a default route."""
+    from datr_amd import gemm
+    ok = gemm.within_kernel_limits
+    # the bench shapes: FFN hidden [88892, 2048] = x [88892, 256] @ w1 [2048, 256].T, and its weight gradient
+    assert ok([(88892, 256), (2048, 256)], [256, 256])
+    assert ok([(88892, 2048), (256, 2048)], [2048, 2048])
+    assert ok([(88892, 2048), (88892, 256)], [2048, 256])
+    # ~12 images of 800 x 1333 in one encoder call: rows x 2048 reaches 2^29
+    assert not ok([(262144, 256), (2048, 256)], [256, 256])
+    assert not ok([(262144, 2048), (256, 2048)], [2048, 2048])
+    # an operand of 2 GiB (a row slice of a very wide matrix: the stride counts)
+    assert not ok([(70000, 256), (256, 256)], [8192, 256])
+    # an output-feature count that is not a multiple of 4 (the NT form's N % 4 rule)
+    assert not ok([(88892, 256), (9, 256)], [256, 256])
+    assert ok([(88892, 256), (12, 256)], [256, 256])
