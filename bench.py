@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
-PMC_RECORD = "r05_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
+PMC_RECORD = "r06_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
 STEP_MFMA_RECORD = "r05_step_mfma.txt"   # in-step matrix-pipe busy per kernel family (committed PMC pass)
 
 
@@ -148,6 +148,24 @@ class MsdaTimer:
                 traffic = int(round((2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024))
                 traffic_src = f"profiles/{PMC_RECORD}: (2 x mean FETCH_SIZE + mean WRITE_SIZE) x 1024, " \
                               f"{len(fetch)} + {len(write)} launches"
+                pipes = rec.get("pipe_counters_mean_per_launch") or {}
+                if all(k in pipes for k in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE")):
+                    # What this instruction stream could reach if its busiest pipe never waited: the launch's time x the
+                    # busy fraction of the vector ALUs / the LDS data path (committed PMC passes of the same launch:
+                    # SQ_ACTIVE_INST_VALU x 4 cycles over 1024 SIMDs, SQ_LDS_IDX_ACTIVE over 256 CUs, against
+                    # GRBM_GUI_ACTIVE / 8 elapsed cycles), and the PMC traffic at the HBM peak.
+                    elapsed = pipes["GRBM_GUI_ACTIVE"] / 8.0
+                    valu = 4.0 * pipes["SQ_ACTIVE_INST_VALU"] / 1024.0 / elapsed
+                    lds = pipes["SQ_LDS_IDX_ACTIVE"] / 256.0 / elapsed
+                    hbm_us = traffic / (HBM_PEAK_GBPS * 1e3)
+                    ceiling_us = max(valu * mean_us, lds * mean_us, hbm_us)
+                    self._ceiling = {
+                        "valu_busy": round(valu, 3), "lds_busy": round(lds, 3),
+                        "valu_us": round(valu * mean_us, 1), "lds_us": round(lds * mean_us, 1), "hbm_us": round(hbm_us, 1),
+                        "ceiling_us": round(ceiling_us, 1), "achieved_over_ceiling": round(ceiling_us / mean_us, 3),
+                        "bound_by": "valu" if ceiling_us == valu * mean_us else "lds" if ceiling_us == lds * mean_us else "hbm",
+                        "source": f"profiles/{PMC_RECORD} pipe_counters_mean_per_launch (rocprofv3 PMC passes of the same "
+                                  "launch shape; busy fractions applied to this run's mean_us)"}
         if self.msda.PYR_FORWARD and D == 32 and K == 16 and self.phased:
             kernel = "msda_fwd_pyr2_d32 (encoder call, csrc/msda_fwd_pyr2.hip: all levels out of LDS windows)"
         elif self.msda.PYR_FORWARD and D == 32 and K == 16:
@@ -159,7 +177,8 @@ class MsdaTimer:
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "kernel": kernel, "launches": len(us),
                 "mean_us": round(mean_us, 2), "algorithmic_bytes": algo_bytes,
-                "empty_event_pair_us": empty_event_pair_us()}
+                "empty_event_pair_us": empty_event_pair_us(),
+                "ceiling": getattr(self, "_ceiling", None)}
 
 
 def empty_event_pair_us(n: int = 64):
@@ -666,7 +685,7 @@ def rank_diagnostics(state, step_diag, elapsed_local, steps, world, device):
     approaches the step time), how long the host then waits for the losses, and the span on the compute
     stream between "last bucket launched" and "every all-reduce done" in reducer.finish() -- the part of the
     gradient exchange NOT overlapped with backward."""
-    mine = {"ms_per_step": round(elapsed_local / steps * 1e3, 2)}
+    mine = {"rank": dist.get_rank() if dist.is_initialized() else 0, "ms_per_step": round(elapsed_local / steps * 1e3, 2)}
     if step_diag:
         d = step_diag[-steps:]
         mine["host_enqueue_ms"] = round(sum(x["host_enqueue_ms"] for x in d) / len(d), 2)
@@ -682,9 +701,14 @@ def rank_diagnostics(state, step_diag, elapsed_local, steps, world, device):
         mine["buckets"] = len(red.buckets)
         mine["allreduce_bytes"] = red.total_bytes
     if world > 1:
-        out = [None] * world
-        dist.all_gather_object(out, mine)
-        return out
+        # every rank reaches this point with the same control flow; a failure of the object gather is symmetric
+        # (all ranks raise) and only costs the per-rank table
+        try:
+            out = [None] * world
+            dist.all_gather_object(out, mine)
+            return out
+        except Exception as exc:  # noqa: BLE001
+            mine["gather_error"] = repr(exc)[:200]
     return [mine]
 
 
@@ -756,8 +780,13 @@ def main():
             "the multi-GPU bench runs over RCCL (torch.distributed backend 'nccl'); --allow-gloo is for tests"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    affinity = pin_to_local_cores(int(os.environ.get("LOCAL_RANK", "0")),
-                                  int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
+    affinity = None
+    if world > 1:
+        try:            # placement is a courtesy: never let it end a scaling run
+            affinity = pin_to_local_cores(int(os.environ.get("LOCAL_RANK", "0")),
+                                          int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        except Exception as exc:  # noqa: BLE001
+            affinity = {"pinned": False, "error": repr(exc)[:200]}
 
     state = build_training(device=device, rank=rank, channels_last=args.channels_last,
                            tuned_gemm=args.tuned_gemm,

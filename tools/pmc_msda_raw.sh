@@ -16,6 +16,13 @@ for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcraw/$C -o run -- \
       python $REPO/tools/bench_msda.py --iters 6 --dist model --n 4 --encoder-only > /tmp/pmcraw/$C.log 2>&1) || true
 done
+# pipe activity of the same launches (round 6: bench.py's `roofline.ceiling`): vector ALU, LDS data path, elapsed cycles
+i=0
+for P in "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1)); rm -rf /tmp/pmcraw/pipes$i
+  (cd /tmp && rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmcraw/pipes$i -o run -- \
+      python $REPO/tools/bench_msda.py --iters 6 --dist model --n 4 --encoder-only > /tmp/pmcraw/pipes$i.log 2>&1) || true
+done
 python - "$OUT" <<'PY'
 import csv, glob, json, re, sys
 out = {"source": "tools/pmc_msda_raw.sh: rocprofv3 --pmc <counter> --kernel-trace, one counter per pass; "
@@ -35,8 +42,21 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for tag, pat in (("forward", "msda_fwd_pyr"), ("backward", "msda_bwd_pyr"), ("backward_dots", "msda_bwd_dots")):
             if pat in k:
                 kern.setdefault(tag, {"kernel": (re.search(r"msda_\w+(<\d+>)?", k) or [k])[0]}).setdefault(c + "_KB_per_launch", []).append(float(r["Counter_Value"]))
+# pipe counters: mean per launch of the forward / backward kernels
+pipes = {}
+for f in glob.glob("/tmp/pmcraw/pipes*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        for tag, pat in (("forward", "msda_fwd_pyr"), ("backward", "msda_bwd_pyr"), ("backward_dots", "msda_bwd_dots")):
+            if pat in k:
+                pipes.setdefault(tag, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+for tag, d in pipes.items():
+    kern.setdefault(tag, {})["pipe_counters_mean_per_launch"] = {c: sum(v) / len(v) for c, v in sorted(d.items())}
+out["pipe_counter_units"] = ("SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: quad-cycles summed over the SIMDs (x 4 = cycles; 1024 SIMDs); "
+                             "SQ_LDS_IDX_ACTIVE: LDS-array cycles summed over the 256 CUs; GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs")
 fw = kern.get("forward", {})
 out["kernel"] = fw.get("kernel")
+out["pipe_counters_mean_per_launch"] = fw.get("pipe_counters_mean_per_launch", {})
 out["FETCH_SIZE_KB_per_launch"] = fw.get("FETCH_SIZE_KB_per_launch", [])
 out["WRITE_SIZE_KB_per_launch"] = fw.get("WRITE_SIZE_KB_per_launch", [])
 out["backward"] = kern.get("backward", {})            # the sorted scatter (grad_value)
