@@ -41,7 +41,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
 PMC_RECORD = "r06_msda_pmc.json"  # raw FETCH_SIZE / WRITE_SIZE rows of the encoder forward launch
-STEP_MFMA_RECORD = "r05_step_mfma.txt"   # in-step matrix-pipe busy per kernel family (committed PMC pass)
+STEP_MFMA_RECORD = "r06_step_mfma.txt"   # in-step matrix-pipe busy per kernel family (committed PMC pass)
 
 
 from datr_amd.training import build_training, run_steps, synthetic_batch  # noqa: E402
@@ -681,8 +681,9 @@ def pin_to_local_cores(local_rank: int, local_world: int):
 
 def rank_diagnostics(state, step_diag, elapsed_local, steps, world, device):
     """What `bench.py --gpus N` says about WHERE a multi-rank step spends its time, per rank (gathered on
-    rank 0): the rank's own time per step, the host's enqueue time per step (the loop is host-bound when this
-    approaches the step time), how long the host then waits for the losses, and the span on the compute
+    rank 0): the rank's own time per step, the host's enqueue wall time per step (includes launch-queue
+    back-pressure) and the enqueueing thread's CPU time per step (the loop is host-bound when THAT approaches the
+    step time), how long the host then waits for the losses, and the span on the compute
     stream between "last bucket launched" and "every all-reduce done" in reducer.finish() -- the part of the
     gradient exchange NOT overlapped with backward."""
     mine = {"rank": dist.get_rank() if dist.is_initialized() else 0, "ms_per_step": round(elapsed_local / steps * 1e3, 2)}
@@ -690,6 +691,7 @@ def rank_diagnostics(state, step_diag, elapsed_local, steps, world, device):
         d = step_diag[-steps:]
         mine["host_enqueue_ms"] = round(sum(x["host_enqueue_ms"] for x in d) / len(d), 2)
         mine["loss_wait_ms"] = round(sum(x["loss_wait_ms"] for x in d) / len(d), 2)
+        mine["host_cpu_ms"] = round(sum(x["host_cpu_ms"] for x in d) / len(d), 2)
     red = state.reducer
     if red is not None and red.diag:
         d = red.diag[-steps:]

@@ -46,7 +46,11 @@ class NestedTensor:
 
 
 def nested_tensor_from_tensor_list(tensor_list: Sequence[Tensor]) -> NestedTensor:
-    """[C,H_i,W_i] images (or one [B,C,H,W] tensor) -> padded batch + mask."""
+    """[C,H_i,W_i] images (or one [B,C,H,W] tensor) -> padded batch + mask.
+    NB a 4-d input is returned AS IS (`.tensors` aliases the caller's batch, in its memory format): the reference
+    builds a fresh zero-padded copy (util/misc.py:387-409) with the same values, so only a caller that modifies
+    `.tensors` in place afterwards could tell -- none on this path does (the augmentation kernels write new tensors,
+    the backbone never writes its input); clone first if you must."""
     if isinstance(tensor_list, Tensor) and tensor_list.dim() == 4:
         # one [B, C, H, W] batch: every image fills it, nothing to pad -- the batch itself with an all-False mask,
         # in the memory format it came in (the reference copies image by image into a new contiguous tensor,

@@ -115,14 +115,11 @@ class FusedClipAdamW(torch.optim.Optimizer):
                     gr = p.grad = torch.empty_like(p).copy_(gr)
                     self._relaid = True
                 dev = p.device
-                # -1 = no used flag for this tensor (the kernel then always updates it); once an order is set a
-                # parameter missing from it would silently follow another parameter's flag: refuse
-                ui = -1
-                if index is not None:
-                    ui = index.get(id(p), -2)
-                    if ui == -2:
-                        raise KeyError("FusedClipAdamW: a parameter with a gradient is missing from the "
-                                       "set_used_order() list")
+                # -1 = no used flag for this tensor: the kernel then always updates it -- what a plain optimizer does, and
+                # the right answer for a parameter the reducer's order does not know (added by add_param_group after
+                # set_used_order, or an optimizer over a superset of the reducer's parameters); it never borrows
+                # another parameter's flag
+                ui = -1 if index is None else index.get(id(p), -1)
                 rows.append((pptr, gr.data_ptr(), m1, m2, stp, numel, lr, wd, ui, 0))
                 n = len(rows) - 1
                 if numel <= piece:
