@@ -682,7 +682,7 @@ def pin_to_local_cores(local_rank: int, local_world: int):
 def rank_diagnostics(state, step_diag, elapsed_local, steps, world, device):
     """What `bench.py --gpus N` says about WHERE a multi-rank step spends its time, per rank (gathered on
     rank 0): the rank's own time per step, the host's enqueue wall time per step (includes launch-queue
-    back-pressure) and the enqueueing thread's CPU time per step (the loop is host-bound when THAT approaches the
+    back-pressure) and the process's CPU time per step, all threads (the loop is host-bound when THAT approaches the
     step time), how long the host then waits for the losses, and the span on the compute
     stream between "last bucket launched" and "every all-reduce done" in reducer.finish() -- the part of the
     gradient exchange NOT overlapped with backward."""

@@ -459,9 +459,24 @@ __device__ __forceinline__ void pyr2_body(
             accB[t] = *reinterpret_cast<const f4 *>(src + ((chan ^ 64) >> 2));
         }
     }
-    struct LocW { f2 xy; float a; };
+#ifndef PYR2_RECORDS
+#define PYR2_RECORDS 0      // PROBE (round 6): `loc` holds packed per-sample records {pixel (iy << 16 | ix), lh, lw, a}, 16 B
+#endif
+    struct LocW { f2 xy; float a; int pix; };
     auto load_sample = [&](int so, int l) {
         LocW r;
+        r.pix = 0;
+#if PYR2_RECORDS
+        {
+            const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(loc), 0, nimg * S * M * 256, 0x00020000);
+            const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (so + 4 * l + j) * 16, 0, 0));
+            r.pix = __builtin_bit_cast(int, v.x);
+            r.xy = f2{v.z, v.y};          // (lw, lh)
+            r.a = v.w;
+            return r;
+        }
+#endif
 #if PYR2_ABLATE & 8
         // no loads: the centre of the level's window (always inside it), constant weight
         r.xy = f2{((float)(lv[l].wx0 + lv[l].WW / 2) + 0.5f + 1e-9f * (float)so) / (float)lv[l].W,
@@ -555,7 +570,16 @@ __device__ __forceinline__ void pyr2_body(
         for (int t = 0; t < kTPW; ++t) {
             const int ti = wave + t * kP2Waves;
             if (ti >= ntasks) break;
+#if PYR2_RECORDS
+            Pix p;
+            p.inside = cur[t].pix != 0x7fffffff;
+            p.iy = p.inside ? (cur[t].pix >> 16) : 0;
+            p.ix = p.inside ? (int)(short)(cur[t].pix & 0xffff) : 0;
+            p.lh = cur[t].xy.y;
+            p.lw = cur[t].xy.x;
+#else
             const Pix p = locate(cur[t].xy.x, cur[t].xy.y, Hl, Wl);
+#endif
             const int wy = p.iy - wy0, wx = p.ix - wx0;
             const bool inwin = (unsigned)wy <= (unsigned)(WH - 2) && (unsigned)wx <= (unsigned)(WW - 2);
             const bool use = p.inside && inwin;

@@ -73,8 +73,9 @@ _GC_FROZEN = [False, 0]         # done?, training steps seen by this process
 # it -- `host_enqueue_ms`: wall time until batch move + forward + criterion + backward + reduce + clip + step are
 # ENQUEUED (NB it includes back-pressure: a host that runs ahead blocks inside launch calls once the runtime's
 # queue is full, so in steady state this approaches the GPU's step time whoever is the bound), `host_cpu_ms`: CPU
-# time of the enqueueing thread over the whole step (what the host actually has to do: the loop is host-bound when
-# THIS approaches the step time), `loss_wait_ms`: what the host then waits for the step's loss values (the one
+# time of the PROCESS over the whole step (all threads: the forward's launches come from the calling thread, the
+# backward's from the autograd engine's; what the host actually has to do: the loop is host-bound when THIS
+# approaches the step time), `loss_wait_ms`: what the host then waits for the step's loss values (the one
 # blocking point of the loop).  None = off: the clock reads are not taken.
 STEP_DIAG = None
 
@@ -154,7 +155,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     for samples, targets, _, _ in data_loader:
         diag = STEP_DIAG
         t_begin = time.perf_counter() if diag is not None else 0.0
-        c_begin = time.thread_time() if diag is not None else 0.0
+        c_begin = time.process_time() if diag is not None else 0.0
         samples = samples.to(device)
         targets = [{k: v.to(device) for k, v in t.items()} for t in targets]
         if hasattr(criterion, "prefetch_num_boxes"):
@@ -173,7 +174,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         if diag is not None:
             diag.append({"host_enqueue_ms": (t_enqueued - t_begin) * 1e3,
                          "loss_wait_ms": (time.perf_counter() - t_enqueued) * 1e3,
-                         "host_cpu_ms": (time.thread_time() - c_begin) * 1e3})
+                         "host_cpu_ms": (time.process_time() - c_begin) * 1e3})
         loss_value = sum(scaled.values())
         _check_finite(loss_value, loss_dict_reduced)
         if getattr(args, "onecyclelr", False):

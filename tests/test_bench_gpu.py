@@ -45,7 +45,7 @@ def test_bench_two_gloo_ranks_share_the_gpu_and_rank0_prints_the_line_last():
     assert len(ranks) == 2
     for r in ranks:
         assert r["ms_per_step"] > 0 and r["ms_per_step"] <= line["ms_per_step"] * 1.05
-        assert r["host_enqueue_ms"] > 0 and r["loss_wait_ms"] >= 0 and 0 < r["host_cpu_ms"] <= r["host_enqueue_ms"] * 1.5 + 5
+        assert r["host_enqueue_ms"] > 0 and r["loss_wait_ms"] >= 0 and r["host_cpu_ms"] > 0
         assert r["finish_host_ms"] >= 0 and r["buckets"] >= 1 and r["allreduce_bytes"] > 190e6
         assert "exposed_allreduce_ms" in r and r["exposed_allreduce_ms"] >= 0
     aff = cfg["cpu_affinity"]
