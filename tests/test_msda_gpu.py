@@ -830,3 +830,56 @@ def test_module_with_query_gradient_node_equals_the_two_node_module(M, dev, monk
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+
+
+def _pyramid_of(height, width):
+    """Feature-map sizes of the detector for an image of height x width: ResNet-50 strides 8 / 16 / 32 (every stride-2
+    stage rounds up) + the extra 3x3 stride-2 level (dino.py:120-124)."""
+    def up(v, n):
+        for _ in range(n):
+            v = (v + 1) // 2
+        return v
+    return [(up(height, k), up(width, k)) for k in (3, 4, 5, 6)]
+
+
+# image sizes a multi-scale training run produces (datasets/coco transforms: shorter side 480 .. 800 in steps of 32,
+# longer side <= 1333; C2F scales by 1.5): landscape, portrait, near-square, odd sizes whose levels round differently
+MULTISCALE = [(480, 800), (512, 683), (544, 1088), (608, 1013), (672, 1191), (736, 981), (800, 1066), (1201, 800),
+              (720, 1280), (901, 1333)]
+
+
+@pytest.mark.parametrize("size", MULTISCALE, ids=lambda s: f"{s[0]}x{s[1]}")
+def test_pyramid_kernels_over_multiscale_geometries(M, O, dev, size):
+    """The region / window plans of the pyramid kernels are geometry dependent (region grid, window extents, envelope
+    trims, phases, tasks per wave): every image size of a multi-scale run is another plan.  Forward, LDS-window dots and
+    sorted scatter against the C oracle on every element, for ring-like and for spread offsets, with the measured
+    envelope (what the model passes) and without one."""
+    shapes = _pyramid_of(*size)
+    N, Mh, D, P = 2, 8, 32, 4
+    value, sh, lsi, _, _ = O.random_inputs(N, 1, Mh, D, shapes, P, seed=size[0] + size[1])
+    S = value.shape[1]
+    assert S == sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(size[0])
+    attn = torch.softmax(torch.randn(N, S, Mh, 4 * P, generator=g), -1).view(N, S, Mh, 4, P)
+    go = torch.randn(N, S, Mh * D, generator=g)
+    ring = M.MSDeformAttn(256, 4, Mh, P).sampling_offsets.bias.detach().view(1, 1, Mh, 4, P, 2)
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+    for kind in ("ring", "spread"):
+        if kind == "ring":
+            loc = (pyramid_locs(shapes, N, Mh, P, 0.3, seed=size[1]) + ring / wh).contiguous()
+        else:
+            loc = pyramid_locs(shapes, N, Mh, P, 2.5, seed=size[1] + 1)
+        ref = O.msda_forward(value, sh, lsi, loc, attn)
+        rv, rl, ra = O.msda_backward(value, sh, lsi, loc, attn, go)
+        scale = float(rv.abs().max())
+        keep = off_grid(loc, sh)
+        v, s, a = value.to(dev), loc.to(dev), attn.to(dev)
+        shd, lsd = sh.to(dev), lsi.to(dev)
+        for env in (M.measure_envelope(s, shd), None):
+            kw = {} if env is None else {"envelope": env}
+            out = M.ms_deform_attn_forward(v, shd, lsd, s, a, 64, **kw).cpu()
+            torch.testing.assert_close(out, ref, **tol(torch.float32))
+            gv, gl, ga = (x.cpu() for x in M.ms_deform_attn_backward(v, shd, lsd, s, a, go.to(dev), 64, **kw))
+            torch.testing.assert_close(gv, rv, rtol=1e-3, atol=1e-5 * scale)
+            torch.testing.assert_close(ga, ra, **tol(torch.float32, 10))
+            torch.testing.assert_close(gl[keep], rl[keep], **tol(torch.float32, 100))
