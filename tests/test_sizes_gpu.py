@@ -147,3 +147,69 @@ def test_config1_shape_source_only_matches_host_run_with_oracle_msda(monkeypatch
         assert abs(loss_d[k] - loss_h[k]) <= 1e-3 * abs(loss_h[k]) + 1e-4, (k, loss_d[k], loss_h[k])
     for key in ("pred_logits", "pred_boxes"):
         torch.testing.assert_close(out_d[key].float().cpu(), out_h[key], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("sizes,nhwc", [(((352, 597), (333, 640)), True), (((415, 333), (415, 333)), True),
+                                        (((301, 517), (352, 480)), False)],
+                         ids=["padded-odd-nhwc", "portrait-unpadded-nhwc", "padded-odd-nchw"])
+def test_odd_sized_da_step_matches_host_run_with_oracle_msda(sizes, nhwc, monkeypatch):
+    """A multi-scale training run hands the model image sizes that are multiples of nothing (datasets/coco transforms:
+    random shorter side, aspect kept) and pairs of different sizes (padded batch, masks, valid ratios).  The whole DA
+    step's forward + criterion on the device -- own convolution kernels with their edge tiles, NHWC GroupNorm, pyramid
+    MSDA plans for that geometry, masks in the encoder -- against the same weights on the host cores with the C oracle
+    as the MSDA op, the device's top-900 selection substituted: losses to 1e-3 relative, logits / boxes to 1e-3."""
+    import copy
+    from datr_amd.nested import nested_tensor_from_tensor_list
+    from helpers import patch_msda_with_oracle
+    dev = torch.device("cuda:0")
+    args, model, criterion, _ = build_model("cuda:0")
+    host_model = copy.deepcopy(model).cpu()
+    if nhwc:
+        model.backbone.to(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(sizes[0][0] + sizes[1][1])
+    imgs = [torch.randn(3, h, w, generator=g) for h, w in sizes]
+    n_gt = 4
+    cxcy = torch.rand(n_gt, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(n_gt, 2, generator=g) * 0.2 + 0.05
+    targets = [{"boxes": torch.cat([cxcy, wh], 1), "labels": torch.randint(1, 9, (n_gt,), generator=g)}]
+    known = 2 * (200 // (2 * n_gt)) * n_gt
+    p = torch.rand(known, generator=g)
+    noise = {"label_p": p, "new_label": torch.randint(0, 9, (int((p < 0.25).sum()),), generator=g),
+             "rand_sign": torch.randint(0, 2, (known, 4), generator=g).float() * 2 - 1,
+             "rand_part": torch.rand(known, 4, generator=g)}
+
+    def run(m, device, selection=None):
+        m.train()
+        criterion.train()
+        m.dn_noise_override = {k: v.clone() for k, v in noise.items()}
+        m.global_proto.zero_()
+        m.Amount.zero_()
+        picked = []
+        own = m.transformer.select_queries
+
+        def select(scores):
+            idx = own(scores) if selection is None else selection.pop(0).to(scores.device)
+            picked.append(idx.cpu())
+            return idx
+        m.transformer.select_queries = select
+        samples = nested_tensor_from_tensor_list([i.to(device) for i in imgs])
+        if nhwc and device.type == "cuda":
+            samples.tensors = samples.tensors.contiguous(memory_format=torch.channels_last)
+        tg = [{k: v.to(device) for k, v in t_.items()} for t_ in targets]
+        out = m(samples, tg)
+        losses = criterion(out, tg)
+        return out, {k: float(v.detach()) for k, v in losses.items()}, picked
+
+    out_d, loss_d, picked = run(model, dev)
+    assert all(np.isfinite(v) for v in loss_d.values()) and len(loss_d) == 82
+    patch_msda_with_oracle(monkeypatch, kind="c")
+    out_h, loss_h, _ = run(host_model, torch.device("cpu"), selection=[p_.clone() for p_ in picked])
+    assert list(loss_d) == list(loss_h)
+    for k in loss_d:
+        if "class_error" in k or "cardinality" in k:
+            continue
+        assert abs(loss_d[k] - loss_h[k]) <= 2e-3 * abs(loss_h[k]) + 2e-4, (k, loss_d[k], loss_h[k])
+    for key in ("pred_logits", "pred_boxes"):
+        torch.testing.assert_close(out_d[key].detach().float().cpu(), out_h[key].detach(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out_d["da_output"]["backbone_DA"].detach().float().cpu(),
+                               out_h["da_output"]["backbone_DA"].detach(), rtol=1e-3, atol=1e-3)
