@@ -692,6 +692,7 @@ def rank_diagnostics(state, step_diag, elapsed_local, steps, world, device):
         mine["host_enqueue_ms"] = round(sum(x["host_enqueue_ms"] for x in d) / len(d), 2)
         mine["loss_wait_ms"] = round(sum(x["loss_wait_ms"] for x in d) / len(d), 2)
         mine["host_cpu_ms"] = round(sum(x["host_cpu_ms"] for x in d) / len(d), 2)
+        mine["host_cpu_main_thread_ms"] = round(sum(x["host_cpu_main_thread_ms"] for x in d) / len(d), 2)
     red = state.reducer
     if red is not None and red.diag:
         d = red.diag[-steps:]

@@ -74,8 +74,9 @@ _GC_FROZEN = [False, 0]         # done?, training steps seen by this process
 # ENQUEUED (NB it includes back-pressure: a host that runs ahead blocks inside launch calls once the runtime's
 # queue is full, so in steady state this approaches the GPU's step time whoever is the bound), `host_cpu_ms`: CPU
 # time of the PROCESS over the whole step (all threads: the forward's launches come from the calling thread, the
-# backward's from the autograd engine's; what the host actually has to do: the loop is host-bound when THIS
-# approaches the step time), `loss_wait_ms`: what the host then waits for the step's loss values (the one
+# backward's from the autograd engine's, and the HIP runtime's own threads poll -- measured ~1.9 cores' worth per
+# rank: the number of cores a rank needs), `host_cpu_main_thread_ms`: the calling thread's share (forward,
+# criterion, optimizer enqueue: the loop is host-bound when the busiest thread approaches the step time), `loss_wait_ms`: what the host then waits for the step's loss values (the one
 # blocking point of the loop).  None = off: the clock reads are not taken.
 STEP_DIAG = None
 
@@ -155,7 +156,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     for samples, targets, _, _ in data_loader:
         diag = STEP_DIAG
         t_begin = time.perf_counter() if diag is not None else 0.0
-        c_begin = time.process_time() if diag is not None else 0.0
+        c_begin = (time.process_time(), time.thread_time()) if diag is not None else (0.0, 0.0)
         samples = samples.to(device)
         targets = [{k: v.to(device) for k, v in t.items()} for t in targets]
         if hasattr(criterion, "prefetch_num_boxes"):
@@ -174,7 +175,8 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         if diag is not None:
             diag.append({"host_enqueue_ms": (t_enqueued - t_begin) * 1e3,
                          "loss_wait_ms": (time.perf_counter() - t_enqueued) * 1e3,
-                         "host_cpu_ms": (time.process_time() - c_begin) * 1e3})
+                         "host_cpu_ms": (time.process_time() - c_begin[0]) * 1e3,
+                         "host_cpu_main_thread_ms": (time.thread_time() - c_begin[1]) * 1e3})
         loss_value = sum(scaled.values())
         _check_finite(loss_value, loss_dict_reduced)
         if getattr(args, "onecyclelr", False):
