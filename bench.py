@@ -31,8 +31,13 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# multi-process GPU work on this platform needs dmabuf IPC (the host driver has no legacy IPC: without it RCCL fails
+# with `hipIpcGetMemHandle: invalid argument`); the launcher's environment normally carries it already -- set it
+# before the HIP runtime starts in case it does not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
