@@ -219,3 +219,39 @@ def test_no_padding_fast_path_is_identical(monkeypatch):
         assert torch.equal(out["pred_boxes"], ref["pred_boxes"])
     mixed = nested_tensor_from_tensor_list([imgs[0], imgs[1][:, :150, :200]])
     assert mixed.padded is True
+
+
+def test_task_configs_match_the_reference_config_files():
+    """`datr_amd.config` against the reference's own config files (build container only: /root/reference is not on
+    the GPU box): every key of config/DA/Cityscapes2FoggyCityscapes/DINO_4scale_C2F.py that the frozen C2F dict
+    carries has the file's value (but for the launch script's overrides, scripts/DINO_train.sh:4-6); the BDD100K
+    file differs from it in `_base_` only and the Sim10k file in `num_classes` / `dn_labelbook_size` only --
+    which is all `bdd_args` / `sim10k_args` change."""
+    import os
+    import pytest
+    from datr_amd import config
+    root = "/root/reference/config/DA"
+    if not os.path.isdir(root):
+        pytest.skip("reference tree not present")
+
+    def load(rel):
+        ns = {}
+        with open(os.path.join(root, rel)) as f:
+            exec(compile(f.read(), rel, "exec"), ns)
+        return {k: v for k, v in ns.items() if not k.startswith("__") and k != "_base_"}
+    c2f = load("Cityscapes2FoggyCityscapes/DINO_4scale_C2F.py")
+    bdd = load("Cityscapes2BDD100k/DINO_4scale_city2BDD100k.py")
+    sim = load("Sim10k2Cityscapes/DINO_4scale_sim2cityscapes.py")
+    assert bdd == c2f
+    assert {k for k in c2f if sim.get(k) != c2f[k]} == {"num_classes", "dn_labelbook_size"}
+    assert sim["num_classes"] == sim["dn_labelbook_size"] == 2
+    script_overrides = {"embed_init_tgt": True, "dn_box_noise_scale": 1.0, "use_ema": False}
+    mine = vars(config.c2f_args())
+    for k, v in c2f.items():
+        if k in mine:
+            assert mine[k] == script_overrides.get(k, v), (k, mine[k], v)
+    s = vars(config.sim10k_args())
+    assert s["num_classes"] == 2 and s["dn_labelbook_size"] == 2
+    assert {k for k in mine if k != "dataset_file" and s[k] != mine[k]} == {"num_classes", "dn_labelbook_size"}
+    b = vars(config.bdd_args())
+    assert {k for k in mine if b[k] != mine[k]} == {"dataset_file"}
